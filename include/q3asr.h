@@ -1,0 +1,122 @@
+/* libq3asr_hip.so -- C-ABI of the MI355X (gfx950) Qwen3-ASR hot path.
+ *
+ * The reference (gabrimatic/qwen3-asr-mlx) is pure Python with no FFI: its hot path is a sequence
+ * of calls into the MLX runtime.  This library is what a maintainer would bind INSTEAD of those
+ * MLX calls (ctypes stub in INTEGRATION.md); each entry point names the reference call site(s) it
+ * replaces (paths relative to src/qwen3_asr_mlx/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; the caller owns all memory;
+ *     nothing here allocates, frees or synchronises; every call is asynchronous on `stream`
+ *     (a hipStream_t passed as void*) and is legal inside hipGraph stream capture;
+ *   - bf16 buffers are passed as void* (16-bit brain-float, row-major);
+ *   - return value: 0 = ok, -1 = bad argument, -2 = HIP launch/runtime error;
+ *     q3asr_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef Q3ASR_H
+#define Q3ASR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int q3asr_version(void);             /* 100 = 0.1.0 */
+const char* q3asr_arch(void);        /* "gfx950" */
+const char* q3asr_last_error(void);
+
+/* ---- audio.py:211-278  log_mel_spectrogram (numpy STFT loop + filterbank matmul) ------------
+ * audio  fp32 [B][audio_stride] zero-padded, lens_dev int32 [B] (samples, >= 160);
+ * window400 fp32 [400] symmetric Hann; twiddle_cs fp64 [400][2] = (cos, sin)(2*pi*i/400);
+ * fb fp32 [128][201]; fb_range int32 [128][2] = [first nonzero, last nonzero + 1);
+ * out fp32 [B][128][Fmax] (frames >= len/160 are written as 0); gmax_key uint32 [B] scratch. */
+int q3asr_log_mel(const float* audio, int64_t audio_stride, const int32_t* lens_dev, int B, int Fmax,
+                  const float* window400, const double* twiddle_cs, const float* fb, const int32_t* fb_range,
+                  float* out, uint32_t* gmax_key, void* stream);
+
+/* ---- encoder.py:254-273  chunking + conv2d1 + GELU -------------------------------------------
+ * mel fp32 [B][128][Fmax]; chunk ci = frames [chunk_f0[ci], +100) of utterance chunk_b[ci];
+ * w9 fp32 [C1][kt][kf]; out bf16 [n_chunks][50][64][C1] (time-major NHWC). */
+int q3asr_conv1_gelu(const float* mel, int Fmax, const int32_t* chunk_b, const int32_t* chunk_f0, int n_chunks,
+                     const float* w9, const float* bias, void* out, int C1, void* stream);
+
+/* ---- encoder.py:274-275  conv2d2 / conv2d3 (+GELU) as implicit GEMM --------------------------
+ * x bf16 [imgs][Hin][Win][Cin]; w bf16 [Cout][3][3][Cin] (tap order = x's spatial dims);
+ * out row m = (img*Hout + oh)*Wout + ow (or row_map[m], <0 = skip); act: 0 none, 1 GELU;
+ * out_kind: 0 bf16, 1 fp32. */
+int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, int Cin, const void* w, int Cout,
+                         const float* bias, int act, void* out, int out_kind, int64_t ldo,
+                         const int32_t* row_map, void* stream);
+
+/* ---- every nn.Linear on the large-M side: encoder.py:74-76,86,118-119,279,320-321;
+ *      decoder.py:92-97,136-138,165 (prefill) ---------------------------------------------------
+ * out[M,N] = epilogue(A[M,K] . W[N,K]^T): + bias fp32[N]; act 0 none / 1 exact GELU /
+ * 2 SwiGLU over 16-row-interleaved (gate,up) weight rows (out has N/2 columns);
+ * res_kind 0 none / 1 fp32 add / 2 bf16 add with MLX rounding (bf16(bf16(acc)+res));
+ * res_mod > 0: residual row = m % res_mod (per-chunk positional embedding, encoder.py:284-286);
+ * row_map: optional destination row per m, <0 = drop (pad-token strip, encoder.py:289-293). */
+int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
+                    const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
+                    void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream);
+
+/* ---- nn.LayerNorm (encoder.py:112,117,319): x fp32 [M][D] -> y bf16 [M][D] ------------------ */
+int q3asr_layernorm_f32_bf16(const float* x, const float* w, const float* b, void* y, int M, int D, float eps,
+                             void* stream);
+
+/* ---- nn.RMSNorm (decoder.py:189,194,251): bf16 -> bf16; row_idx optional source-row gather -- */
+int q3asr_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const int32_t* row_idx,
+                       int M, int D, float eps, void* stream);
+
+/* ---- mx.fast.scaled_dot_product_attention (encoder.py:82-84 with the block mask of :210-229;
+ *      decoder.py:158-163 prefill) ---------------------------------------------------------------
+ * Independent segments s: Q/O rows [seg_q_start[s], +seg_len[s]); keys 0..seg_len[s]-1 at
+ * K/V + kv_seg_off[s] + kv_head*kv_head_stride + key*kv_row_stride (elements). */
+int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, const void* V, const int64_t* kv_seg_off,
+                   int64_t kv_head_stride, int64_t kv_row_stride, void* O, int64_t o_stride,
+                   const int32_t* seg_q_start, const int32_t* seg_len, int n_segs, int max_len, int n_heads,
+                   int n_kv_heads, int head_dim, int causal, float scale, void* stream);
+
+/* ---- generate.py:20-81  prepare_inputs ------------------------------------------------------- */
+int q3asr_embed_merge(const int32_t* ids, const int32_t* audio_src, const void* E, const float* enc, void* out,
+                      int M, int H, void* stream);
+
+/* ---- decoder.py:140-156  per-head QK-RMSNorm + nn.RoPE + KVCache.update ----------------------
+ * qkv: bf16 [M][ld] (is_slab=0) or fp32 split-K slabs [n_slabs][..] (is_slab=1, ld/slab_stride in
+ * floats); q_out bf16 [M][nh*128]; caches bf16 [B][nkv][Lmax][128] of ONE layer;
+ * row_b/row_pos int32 [M]: sequence and absolute position of each row. */
+int q3asr_qk_norm_rope_kv(const void* qkv, int is_slab, int64_t ld, int n_slabs, int64_t slab_stride,
+                          const int32_t* row_b, const int32_t* row_pos, const void* qn_w, const void* kn_w,
+                          const float* inv_freq, float eps, void* q_out, void* k_cache, void* v_cache, int M,
+                          int nh, int nkv, int head_dim, int Lmax, void* stream);
+
+/* ---- decode step (generate.py:289-313 -> decoder.py:219-253 at T=1), M = batch <= 64 --------- */
+int q3asr_embed_rmsnorm(const int32_t* tok, const void* E, void* h_out, const void* w, void* x_out, int M, int N,
+                        float eps, void* stream);
+/* C = X[M,K] . W[N,K]^T, weight-streaming; n_splits>1 writes fp32 slabs [n_splits][M][N]. */
+int q3asr_skinny_gemm(const void* X, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, int n_splits,
+                      float* slab, void* out, int64_t ldo, void* stream);
+int q3asr_slab_residual_rmsnorm(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
+                                const void* w, void* x_out, int M, int N, float eps, void* stream);
+int q3asr_slab_swiglu(const float* slab, int n_slabs, int64_t slab_stride, void* act, int M, int I, void* stream);
+int q3asr_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
+                      int B, int nh, int nkv, int head_dim, int Lmax, float scale, void* stream);
+
+/* ---- generate.py:88-215 `sample` + loop bookkeeping :286-313, one launch per step ------------ */
+int q3asr_sample_step(const void* logits, int64_t ld, int B, int V, int32_t* out_tokens, int max_out,
+                      int32_t* n_gen, int32_t* finished, int32_t* cur_tok, int32_t* pos, const int32_t* max_new,
+                      float temperature, float top_p, int top_k, float penalty, int ctx, uint64_t seed,
+                      int eos0, int eos1, void* stream);
+
+/* ---- hipGraph capture of the decode step; HIP events on an explicit stream -------------------- */
+int q3asr_graph_begin(void* stream);
+int q3asr_graph_end(void* stream, void** graph_exec_out);
+int q3asr_graph_launch(void* graph_exec, void* stream);
+int q3asr_graph_destroy(void* graph_exec);
+int q3asr_event_create(void** ev);
+int q3asr_event_record(void* ev, void* stream);
+int q3asr_event_elapsed_ms(void* start, void* stop, float* ms);
+int q3asr_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q3ASR_H */

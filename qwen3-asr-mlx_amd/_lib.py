@@ -1,0 +1,91 @@
+"""ctypes binding of libq3asr_hip.so (include/q3asr.h).  No CPU fallback: if the library is
+missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libq3asr_hip.so"
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGS = {
+    "q3asr_version": [],
+    "q3asr_arch": [],
+    "q3asr_last_error": [],
+    "q3asr_log_mel": [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "q3asr_conv1_gelu": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "q3asr_conv3x3s2_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _vp],
+    "q3asr_gemm_bf16": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _i, _i64, _vp, _vp],
+    "q3asr_layernorm_f32_bf16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "q3asr_rmsnorm_bf16": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _f, _vp],
+    "q3asr_attn_fwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "q3asr_embed_merge": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "q3asr_qk_norm_rope_kv": [_vp, _i, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "q3asr_embed_rmsnorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "q3asr_skinny_gemm": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _vp],
+    "q3asr_slab_residual_rmsnorm": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "q3asr_slab_swiglu": [_vp, _i, _i64, _vp, _i, _i, _vp],
+    "q3asr_attn_decode": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "q3asr_sample_step": [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _u64, _i, _i, _vp],
+    "q3asr_graph_begin": [_vp],
+    "q3asr_graph_end": [_vp, C.POINTER(_vp)],
+    "q3asr_graph_launch": [_vp, _vp],
+    "q3asr_graph_destroy": [_vp],
+    "q3asr_event_create": [C.POINTER(_vp)],
+    "q3asr_event_record": [_vp, _vp],
+    "q3asr_event_elapsed_ms": [_vp, _vp, C.POINTER(_f)],
+    "q3asr_event_destroy": [_vp],
+}
+_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p}
+EXPORTS = tuple(_SIGS)
+
+
+class Q3AsrError(RuntimeError):
+    pass
+
+
+def load():
+    """Return the loaded library (loading it on first use).  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not LIB_PATH.exists():
+                    raise Q3AsrError(
+                        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+                lib = C.CDLL(str(LIB_PATH))
+                for name, args in _SIGS.items():
+                    fn = getattr(lib, name)
+                    fn.argtypes = args
+                    fn.restype = _RESTYPES.get(name, C.c_int)
+                _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().q3asr_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise Q3AsrError(f"{what}: {msg} (rc={rc})")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

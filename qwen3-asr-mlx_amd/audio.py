@@ -1,0 +1,194 @@
+"""Audio I/O and the HIP log-mel frontend (mirror of reference audio.py).
+
+`log_mel_spectrogram` keeps the reference signature (audio.py:238-246) and returns a
+``torch.Tensor`` on the GPU instead of an ``mx.array``.  The arithmetic runs in
+``q3asr_log_mel`` (csrc/mel.hip); the constant tables (Hann window, DFT twiddles, the
+reference's HTK-scale / width-normalised filterbank with its four dead rows) are built here
+once per parameter set and kept on the device.
+"""
+from __future__ import annotations
+
+import struct
+import threading
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+SAMPLE_RATE = 16_000
+N_FFT = 400
+HOP_LENGTH = 160
+N_MELS = 128
+F_MIN = 0.0
+F_MAX = 8_000.0
+
+_mel_filterbank_cache: dict[tuple, np.ndarray] = {}
+_frontends: dict[tuple, "MelFrontend"] = {}
+_cache_lock = threading.Lock()
+
+
+def _get_mel_filterbank(n_fft: int = N_FFT, n_mels: int = N_MELS, sample_rate: int = SAMPLE_RATE,
+                        f_min: float = F_MIN, f_max: float = F_MAX) -> np.ndarray:
+    """(n_mels, n_fft//2+1) float32 triangles, cached per parameter tuple (audio.py:41-96).
+    Mel scale 2595*log10(1+f/700); rows scaled by 1/(f_right - f_left)."""
+    key = (n_fft, n_mels, sample_rate, f_min, f_max)
+    fb = _mel_filterbank_cache.get(key)
+    if fb is None:
+        n_bins = n_fft // 2 + 1
+        hz = np.linspace(0.0, sample_rate / 2.0, n_bins)
+        mel_lo = 2595.0 * np.log10(1.0 + f_min / 700.0)
+        mel_hi = 2595.0 * np.log10(1.0 + f_max / 700.0)
+        pts = 700.0 * (10.0 ** (np.linspace(mel_lo, mel_hi, n_mels + 2) / 2595.0) - 1.0)
+        fb = np.zeros((n_mels, n_bins), dtype=np.float32)
+        for m in range(n_mels):
+            left, centre, right = pts[m], pts[m + 1], pts[m + 2]
+            rise = (hz - left) / (centre - left)
+            fall = (right - hz) / (right - centre)
+            fb[m] = np.maximum(0.0, np.minimum(rise, fall))
+            if right - left > 0.0:
+                fb[m] /= (right - left)
+        _mel_filterbank_cache[key] = fb
+    return fb
+
+
+# --------------------------------------------------------------------------- audio files
+def _read_wav_pcm(path: str | Path) -> tuple[np.ndarray, int]:
+    """RIFF fast path: PCM16 / PCM32 / float32, interleaved channels averaged (audio.py:103-170)."""
+    with open(path, "rb") as f:
+        if f.read(4) != b"RIFF":
+            raise ValueError("Not a RIFF file")
+        f.read(4)
+        if f.read(4) != b"WAVE":
+            raise ValueError("Not WAVE")
+        fmt = None
+        data_at = data_len = None
+        while True:
+            cid = f.read(4)
+            if len(cid) < 4:
+                break
+            (size,) = struct.unpack("<I", f.read(4))
+            if cid == b"fmt ":
+                fmt = f.read(size)
+            else:
+                if cid == b"data":
+                    data_at, data_len = f.tell(), size
+                f.seek(size, 1)
+        if fmt is None or data_at is None:
+            raise ValueError("Missing fmt or data chunk")
+        tag, channels, rate = struct.unpack_from("<HHI", fmt, 0)
+        bits = struct.unpack_from("<H", fmt, 14)[0]
+        if tag not in (1, 3):
+            raise ValueError(f"Unsupported audio format: {tag}")
+        f.seek(data_at)
+        raw = f.read(data_len)
+    n = data_len // (bits // 8) // channels
+    if tag == 1 and bits == 16:
+        x = np.frombuffer(raw, dtype=np.int16).astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 32:
+        x = np.frombuffer(raw, dtype=np.int32).astype(np.float32) / 2147483648.0
+    elif tag == 3 and bits == 32:
+        x = np.frombuffer(raw, dtype=np.float32).copy()
+    else:
+        raise ValueError(f"Unsupported PCM depth: {bits}-bit")
+    if channels > 1:
+        x = x[: n * channels].reshape(n, channels).mean(axis=1)
+    return x.astype(np.float32), rate
+
+
+def load_audio(path: str | Path, target_sr: int = SAMPLE_RATE) -> np.ndarray:
+    """Mono float32 at target_sr; WAV natively, soundfile otherwise, linear-interp resample
+    with target_len = int(len * target_sr / sr) (audio.py:173-204)."""
+    path = Path(path)
+    samples: Optional[np.ndarray] = None
+    sr: Optional[int] = None
+    if path.suffix.lower() == ".wav":
+        try:
+            samples, sr = _read_wav_pcm(path)
+        except Exception:
+            samples = None
+    if samples is None:
+        import soundfile as sf
+        samples, sr = sf.read(str(path), dtype="float32", always_2d=False)
+        if samples.ndim == 2:
+            samples = samples.mean(axis=1)
+    if sr != target_sr:
+        n_out = int(len(samples) * target_sr / sr)
+        samples = np.interp(np.linspace(0.0, len(samples) - 1, n_out), np.arange(len(samples)), samples).astype(np.float32)
+    return samples
+
+
+# --------------------------------------------------------------------------- HIP frontend
+class MelFrontend:
+    """Device-resident tables + batched launch of q3asr_log_mel."""
+
+    def __init__(self, device, sample_rate: int = SAMPLE_RATE, f_min: float = F_MIN, f_max: float = F_MAX):
+        import torch
+        self.device = torch.device(device)
+        fb = _get_mel_filterbank(N_FFT, N_MELS, sample_rate, f_min, f_max)
+        rng = np.zeros((N_MELS, 2), dtype=np.int32)
+        for m in range(N_MELS):
+            nz = np.nonzero(fb[m])[0]
+            if len(nz):
+                rng[m] = (nz[0], nz[-1] + 1)
+        ang = 2.0 * np.pi * np.arange(N_FFT, dtype=np.float64) / N_FFT
+        tw = np.stack([np.cos(ang), np.sin(ang)], axis=1)
+        self.fb = torch.from_numpy(fb).to(self.device)
+        self.fb_range = torch.from_numpy(rng).to(self.device)
+        self.window = torch.from_numpy(np.hanning(N_FFT).astype(np.float32)).to(self.device)
+        self.twiddle = torch.from_numpy(tw).to(self.device)
+
+    def __call__(self, audio, lens, lens_host: Sequence[int]):
+        """audio fp32 [B][stride] (device, zero padded), lens int32 [B] (device).
+        Returns (mel fp32 [B][128][Fmax], n_frames list)."""
+        import torch
+        B = audio.shape[0]
+        if min(lens_host) < HOP_LENGTH:
+            raise ValueError(f"audio shorter than one hop ({HOP_LENGTH} samples) has no mel frames")
+        n_frames = [int(n) // HOP_LENGTH for n in lens_host]
+        fmax = max(n_frames)
+        out = torch.empty((B, N_MELS, fmax), dtype=torch.float32, device=self.device)
+        gkey = torch.empty((B,), dtype=torch.int32, device=self.device)
+        _lib.call("q3asr_log_mel", _lib.ptr(audio), audio.stride(0), _lib.ptr(lens), B, fmax, _lib.ptr(self.window),
+                  _lib.ptr(self.twiddle), _lib.ptr(self.fb), _lib.ptr(self.fb_range), _lib.ptr(out), _lib.ptr(gkey),
+                  _lib.stream_ptr())
+        return out, n_frames
+
+
+def get_frontend(device=None, sample_rate: int = SAMPLE_RATE, f_min: float = F_MIN, f_max: float = F_MAX) -> MelFrontend:
+    import torch
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    key = (str(dev), sample_rate, f_min, f_max)
+    with _cache_lock:
+        fe = _frontends.get(key)
+        if fe is None:
+            fe = _frontends[key] = MelFrontend(dev, sample_rate, f_min, f_max)
+    return fe
+
+
+def pack_audio(batch: Sequence[np.ndarray], device):
+    """Host list of 1-D float32 arrays -> (padded device tensor [B][Lmax], lens device, lens host)."""
+    import torch
+    lens = [int(len(a)) for a in batch]
+    lmax = max(lens)
+    host = torch.zeros((len(batch), lmax), dtype=torch.float32, pin_memory=torch.cuda.is_available())
+    for i, a in enumerate(batch):
+        host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    dev = host.to(device, non_blocking=True)
+    lens_dev = torch.tensor(lens, dtype=torch.int32).to(device, non_blocking=True)
+    return dev, lens_dev, lens
+
+
+def log_mel_spectrogram(audio, n_fft: int = N_FFT, hop_length: int = HOP_LENGTH, n_mels: int = N_MELS,
+                        sample_rate: int = SAMPLE_RATE, f_min: float = F_MIN, f_max: float = F_MAX):
+    """Log-mel spectrogram of one utterance, shape (n_mels, n_frames), float32 on the GPU.
+    Same steps as reference audio.py:238-278."""
+    if (n_fft, hop_length, n_mels) != (N_FFT, HOP_LENGTH, N_MELS):
+        raise NotImplementedError("the HIP frontend is specialised for n_fft=400, hop_length=160, n_mels=128")
+    if not isinstance(audio, np.ndarray):
+        audio = load_audio(audio, target_sr=sample_rate)
+    fe = get_frontend(None, sample_rate, f_min, f_max)
+    dev, lens_dev, lens = pack_audio([np.asarray(audio, dtype=np.float32)], fe.device)
+    mel, _ = fe(dev, lens_dev, lens)
+    return mel[0]

@@ -1,0 +1,49 @@
+"""Build libq3asr_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+LIB = HERE / "libq3asr_hip.so"
+SOURCES = ["core.hip", "mel.hip", "gemm.hip", "norm.hip", "elementwise.hip", "attn.hip", "skinny.hip", "sampling.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-I", str(HERE.parent / "include")]
+
+
+def _stale(obj: Path, deps) -> bool:
+    return (not obj.exists()) or any(d.stat().st_mtime > obj.stat().st_mtime for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = HERE / "build"
+    objdir.mkdir(exist_ok=True)
+    common = [CSRC / "common.h", HERE.parent / "include" / "q3asr.h", Path(__file__)]
+    jobs = []
+    for s in SOURCES:
+        src, obj = CSRC / s, objdir / (s + ".o")
+        if force or _stale(obj, [src] + common):
+            jobs.append([hipcc, *FLAGS, "-c", str(src), "-o", str(obj)])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [str(objdir / (s + ".o")) for s in SOURCES]
+    if force or jobs or not LIB.exists():
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,292 @@
+// Attention kernels (mx.fast.scaled_dot_product_attention call sites):
+//  * attn_fwd<HD, CAUSAL>: flash-style forward over independent segments.
+//      - encoder (encoder.py:82-84): HD=64, bidirectional, one segment per 104-token window
+//        (the block-diagonal mask of encoder.py:210-229 is never materialised);
+//      - decoder prefill (decoder.py:158-163): HD=128, causal, GQA, one segment per sequence,
+//        K/V read from the KV cache the RoPE kernel just filled.
+//  * attn_decode: one new token per sequence against its cache (HBM-bound KV streaming).
+//
+// attn_fwd maths per 64-key tile, per wave (16 query rows), MFMA 16x16x32 bf16:
+//   S^T = K . Q^T      A operand = K rows (ds_read_b128 from the swizzled LDS tile), B = Q (registers)
+//                      -> lane (g=lane>>4, li=lane&15) holds S[key=16*kt4+4g+r][q=li]: a query's scores
+//                         live in 4 lanes, so row max/sum need two shuffles (xor 16, 32) only.
+//   O^T += V^T . P^T   B operand = P straight from the S registers (bf16), with the k index of the
+//                      MFMA re-labelled key(c,g,j) = 32c + 16(j>>2) + 4g + (j&3); A operand = V^T
+//                      gathered with that same labelling by two ds_read_b64_tr_b16 per fragment.
+//                      -> O^T[d=16dt+4g+r][q=li]: the softmax rescale is lane-local.
+// Softmax in fp32; P rounded to bf16 for the PV MFMA; the row sum uses unrounded P.
+#include "common.h"
+
+#define KV_TILE 64
+
+template <int HD> struct TileImg;
+// 256-byte rows: 16-byte chunk ch of row r sits at 256 r + 16 (ch ^ f(r)); conflict-free for row reads
+// and transposed reads (cdna_hip_programming.md T10 image (b)).
+template <> struct TileImg<128> {
+    static __device__ __forceinline__ int off(int row, int ch) {
+        return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    }
+};
+template <> struct TileImg<64> {
+    static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ (row & 7)); }
+};
+
+struct AttnParams {
+    const bf16* Q; long q_stride;          // row stride (elements); head h at column h*HD
+    const bf16* K; const bf16* V;
+    const long* kv_seg_off;                // per segment: element offset of (key 0, kv head 0)
+    long kv_head_stride, kv_row_stride;
+    bf16* O; long o_stride;
+    const int* seg_q_start;                // first Q/O row of the segment
+    const int* seg_len;
+    int group;                             // query heads per kv head
+    float scale;
+};
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * KV_TILE * HD * 2];
+    char* sK = smem;
+    char* sV = smem + KV_TILE * HD * 2;
+    const int seg = blockIdx.z, head = blockIdx.y, qt = blockIdx.x;
+    const int len = p.seg_len[seg];
+    if (qt * 64 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int q_abs = qt * 64 + wave * 16 + li;
+    const int q_eff = min(q_abs, len - 1);
+    const long qrow = (long)p.seg_q_start[seg] + q_eff;
+    constexpr int KS = HD / 32;            // k-steps of the S MFMA
+    constexpr int DT = HD / 16;            // 16-wide d tiles of O^T
+    constexpr int CPR = HD / 8;            // 16-byte chunks per row
+
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(p.Q + qrow * p.q_stride + head * HD + 32 * ks + 8 * g);
+
+    const bf16* Kb = p.K + p.kv_seg_off[seg] + (long)(head / p.group) * p.kv_head_stride;
+    const bf16* Vb = p.V + p.kv_seg_off[seg] + (long)(head / p.group) * p.kv_head_stride;
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int n_tiles = CAUSAL ? (qt + 1) : (len + KV_TILE - 1) / KV_TILE;
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        __syncthreads();
+        // stage K and V tile: KV_TILE*CPR chunks each, 256 threads
+#pragma unroll
+        for (int it = 0; it < KV_TILE * CPR / 256; ++it) {
+            const int c = tid + 256 * it;
+            const int row = c / CPR, ch = c - row * CPR;
+            const int key = min(kt * KV_TILE + row, len - 1);
+            const uint4 kv = *reinterpret_cast<const uint4*>(Kb + (long)key * p.kv_row_stride + ch * 8);
+            const uint4 vv = *reinterpret_cast<const uint4*>(Vb + (long)key * p.kv_row_stride + ch * 8);
+            *reinterpret_cast<uint4*>(sK + TileImg<HD>::off(row, ch)) = kv;
+            *reinterpret_cast<uint4*>(sV + TileImg<HD>::off(row, ch)) = vv;
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T
+        f32x4 s[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            s[k4] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + TileImg<HD>::off(16 * k4 + li, 4 * ks + g));
+                s[k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[k4], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (row = query li, spread over the 4 lane groups)
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * KV_TILE + 16 * k4 + 4 * g + r;
+                const bool ok = key < len && (!CAUSAL || key <= q_eff);
+                const float v = ok ? s[k4][r] * p.scale : -INFINITY;
+                s[k4][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);          // finite: key 0 is visible to every query
+        const float alpha = __expf(m_run - m_new);       // m_run = -inf on the first tile -> 0
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(s[k4][r] - m_new);
+                psum += pv;
+                pf[k4 >> 1][(k4 & 1) * 4 + r] = f2bf(pv);
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
+        // ---- O^T += V^T P^T
+        const int q4 = li >> 2, p4 = li & 3;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int ch = 2 * dt + (p4 >> 1);
+                const int r_lo = 32 * c + 4 * g + q4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sV + TileImg<HD>::off(r_lo, ch) + 8 * (p4 & 1)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sV + TileImg<HD>::off(r_lo + 16, ch) + 8 * (p4 & 1)));
+                union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+                u.h.a = lo;
+                u.h.b = hi;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[c], o[dt], 0, 0, 0);
+            }
+        }
+    }
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    if (q_abs < len) {
+        const float inv = 1.0f / l_tot;
+        bf16* orow = p.O + ((long)p.seg_q_start[seg] + q_abs) * p.o_stride + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = f2bf(o[dt][r] * inv);
+            *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g) = ov;
+        }
+    }
+}
+
+extern "C" int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, const void* V, const int64_t* kv_seg_off,
+                              int64_t kv_head_stride, int64_t kv_row_stride, void* O, int64_t o_stride,
+                              const int32_t* seg_q_start, const int32_t* seg_len, int n_segs, int max_len, int n_heads,
+                              int n_kv_heads, int head_dim, int causal, float scale, void* stream) {
+    Q3_REQUIRE(Q && K && V && kv_seg_off && O && seg_q_start && seg_len, "attn_fwd: null pointer");
+    Q3_REQUIRE(n_segs > 0 && max_len > 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "attn_fwd: bad sizes");
+    Q3_REQUIRE(q_stride % 8 == 0 && kv_row_stride % 8 == 0 && kv_head_stride % 8 == 0 && o_stride % 4 == 0, "attn_fwd: strides must keep 16-byte alignment");
+    AttnParams p;
+    p.Q = (const bf16*)Q; p.q_stride = q_stride; p.K = (const bf16*)K; p.V = (const bf16*)V;
+    p.kv_seg_off = (const long*)kv_seg_off; p.kv_head_stride = kv_head_stride; p.kv_row_stride = kv_row_stride;
+    p.O = (bf16*)O; p.o_stride = o_stride; p.seg_q_start = seg_q_start; p.seg_len = seg_len;
+    p.group = n_heads / n_kv_heads; p.scale = scale;
+    dim3 grid((max_len + 63) / 64, n_heads, n_segs), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 64 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, blk, 0, s, p);
+    else if (head_dim == 128 && causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, blk, 0, s, p);
+    else if (head_dim == 128 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, blk, 0, s, p);
+    else if (head_dim == 64 && causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, blk, 0, s, p);
+    else { q3asr_set_error("attn_fwd: head_dim=%d unsupported (64 or 128)", head_dim); return Q3_EBADARG; }
+    return q3_check_launch("attn_fwd");
+}
+
+// ---------------------------------------------------------------------------
+// Decode attention: one query token per sequence, 2 query heads per kv head (GQA 16/8),
+// keys 0..pos[b] of the cache.  One 512-thread workgroup per (kv head, sequence); a 16-lane
+// group owns one cached token per step (lane i: dims 8i..8i+7, one 16-byte load of K and of V),
+// so a wave-instruction reads 4 whole 256-byte rows.  Each group keeps an online-softmax
+// partial; the 32 partials are merged through LDS.  Bytes: 2 * 256 B per cached token per
+// kv head -- 114,688 B per token over 28 layers.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void attn_decode_kernel(const bf16* __restrict__ q /*[B][nh*128]*/,
+                                                          const bf16* __restrict__ k_cache, const bf16* __restrict__ v_cache,
+                                                          const int* __restrict__ pos, bf16* __restrict__ out, int nh,
+                                                          int nkv, int Lmax, float scale) {
+    __shared__ float s_m[32][2], s_l[32][2];
+    __shared__ __attribute__((aligned(16))) float s_acc[32][2][128];
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int L = pos[b] + 1;
+    const bf16* Kb = k_cache + ((long)b * nkv + kvh) * Lmax * 128;
+    const bf16* Vb = v_cache + ((long)b * nkv + kvh) * Lmax * 128;
+    float q0[8], q1[8];
+    {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(q + (long)b * nh * 128 + (2 * kvh) * 128 + 8 * i);
+        const bf16x8 c = *reinterpret_cast<const bf16x8*>(q + (long)b * nh * 128 + (2 * kvh + 1) * 128 + 8 * i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { q0[e] = bf2f(a[e]); q1[e] = bf2f(c[e]); }
+    }
+    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+    const int slot = wave * 4 + g;                       // 32 token slots per sweep
+    for (int t0 = 0; t0 < L; t0 += 64) {
+        // two tokens per group per iteration keeps 4 x 16 B per lane in flight
+        bf16x8 kk[2], vv[2];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = t0 + 32 * u + slot;
+            ok[u] = t < L;
+            const int tc = ok[u] ? t : 0;
+            kk[u] = *reinterpret_cast<const bf16x8*>(Kb + (long)tc * 128 + 8 * i);
+            vv[u] = *reinterpret_cast<const bf16x8*>(Vb + (long)tc * 128 + 8 * i);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float kf = bf2f(kk[u][e]);
+                d0 = fmaf(q0[e], kf, d0);
+                d1 = fmaf(q1[e], kf, d1);
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                d0 += __shfl_xor(d0, o, 64);
+                d1 += __shfl_xor(d1, o, 64);
+            }
+            if (ok[u]) {
+                const float s0 = d0 * scale, s1 = d1 * scale;
+                const float n0 = fmaxf(m0, s0), n1 = fmaxf(m1, s1);
+                const float al0 = __expf(m0 - n0), al1 = __expf(m1 - n1);
+                const float p0 = __expf(s0 - n0), p1 = __expf(s1 - n1);
+                l0 = l0 * al0 + p0;
+                l1 = l1 * al1 + p1;
+                m0 = n0;
+                m1 = n1;
+                const float pb0 = round_bf(p0), pb1 = round_bf(p1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float vf = bf2f(vv[u][e]);
+                    a0[e] = fmaf(pb0, vf, a0[e] * al0);
+                    a1[e] = fmaf(pb1, vf, a1[e] * al1);
+                }
+            }
+        }
+    }
+    if (i == 0) { s_m[slot][0] = m0; s_m[slot][1] = m1; s_l[slot][0] = l0; s_l[slot][1] = l1; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s_acc[slot][0][8 * i + e] = a0[e]; s_acc[slot][1][8 * i + e] = a1[e]; }
+    __syncthreads();
+    if (tid < 256) {
+        const int h = tid >> 7, d = tid & 127;
+        float M = -INFINITY;
+        for (int s = 0; s < 32; ++s) M = fmaxf(M, s_m[s][h]);
+        float num = 0.f, den = 0.f;
+        for (int s = 0; s < 32; ++s) {
+            const float w = __expf(s_m[s][h] - M);       // empty partial: exp(-inf) = 0
+            num = fmaf(s_acc[s][h][d], w, num);
+            den = fmaf(s_l[s][h], w, den);
+        }
+        out[(long)b * nh * 128 + (2 * kvh + h) * 128 + d] = f2bf(num / den);
+    }
+}
+
+extern "C" int q3asr_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
+                                 int B, int nh, int nkv, int head_dim, int Lmax, float scale, void* stream) {
+    Q3_REQUIRE(q && k_cache && v_cache && pos && out, "attn_decode: null pointer");
+    Q3_REQUIRE(head_dim == 128 && nh == 2 * nkv, "attn_decode: needs head_dim 128 and 2 query heads per kv head (got %d, %d/%d)", head_dim, nh, nkv);
+    Q3_REQUIRE(B > 0 && Lmax > 0, "attn_decode: bad sizes");
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(nkv, B), dim3(512), 0, (hipStream_t)stream, (const bf16*)q, (const bf16*)k_cache,
+                       (const bf16*)v_cache, pos, (bf16*)out, nh, nkv, Lmax, scale);
+    return q3_check_launch("attn_decode");
+}

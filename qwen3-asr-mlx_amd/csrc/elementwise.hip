@@ -1,0 +1,186 @@
+// Small fused kernels around the GEMMs: conv stem layer 1 (direct), prompt
+// embedding merge, per-head QK-RMSNorm + RoPE + KV-cache append.  All HBM-bound.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// conv2d1: Conv2d(1 -> C1, k3 s2 p1) + exact GELU over 100-frame mel chunks
+// (encoder.py:148-154,254-273).  Input is the normalised log-mel [B][128][Fmax]
+// fp32; chunk ci covers frames [f0, f0+100) of utterance chunk_b[ci], zero beyond
+// the utterance (encoder.py:262-266; the normalise kernel wrote those zeros).
+// Output layout is TIME-major NHWC: act[ci][ot 50][of 64][C1] bf16, so that after
+// three convs a token's 16x480 features are one contiguous GEMM row (the
+// reference's transpose at encoder.py:278 is folded into conv_out's weight order).
+// K = 9 per output: direct fp32 FMAs; traffic = 2*C1 bytes written per output pixel.
+// ---------------------------------------------------------------------------
+#define C1_TIN 100
+#define C1_FIN 128
+
+__global__ __launch_bounds__(256) void conv1_gelu_kernel(const float* __restrict__ mel, int Fmax,
+                                                         const int* __restrict__ chunk_b, const int* __restrict__ chunk_f0,
+                                                         const float* __restrict__ w9 /*[C1][kt][kf]*/,
+                                                         const float* __restrict__ bias, bf16* __restrict__ out, int C1) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* in_s = sm;                    // [3][130]  (f = -1 .. 128)
+    float* w_s = sm + 3 * 130;           // [9][C1]
+    float* b_s = w_s + 9 * C1;           // [C1]
+    const int ci = blockIdx.y, ot = blockIdx.x;
+    const int TOUT = (C1_TIN - 1) / 2 + 1, FOUT = (C1_FIN - 1) / 2 + 1;
+    const int b = chunk_b[ci], f0 = chunk_f0[ci];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * 130; i += 256) {
+        const int kt = i / 130, fp = i - kt * 130;
+        const int t = 2 * ot - 1 + kt, f = fp - 1;
+        float v = 0.f;
+        if (t >= 0 && t < C1_TIN && f >= 0 && f < C1_FIN && f0 + t < Fmax)
+            v = mel[((long)b * C1_FIN + f) * Fmax + f0 + t];
+        in_s[i] = v;
+    }
+    for (int i = tid; i < 9 * C1; i += 256) {
+        const int co = i / 9, tap = i - co * 9;
+        w_s[tap * C1 + co] = w9[i];
+    }
+    for (int i = tid; i < C1; i += 256) b_s[i] = bias[i];
+    __syncthreads();
+    const int octs = C1 / 8;
+    bf16* obase = out + ((long)(ci * TOUT + ot) * FOUT) * C1;
+    for (int item = tid; item < FOUT * octs; item += 256) {
+        const int of = item / octs, c8 = (item - of * octs) * 8;
+        float x[9];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) x[kt * 3 + kf] = in_s[kt * 130 + 2 * of + kf];   // f = 2*of-1+kf -> index +1
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = b_s[c8 + e];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) a = fmaf(w_s[tap * C1 + c8 + e], x[tap], a);
+            o[e] = f2bf(gelu_erf(a));
+        }
+        *reinterpret_cast<bf16x8*>(obase + (long)of * C1 + c8) = o;
+    }
+}
+
+extern "C" int q3asr_conv1_gelu(const float* mel, int Fmax, const int32_t* chunk_b, const int32_t* chunk_f0, int n_chunks,
+                                const float* w9, const float* bias, void* out, int C1, void* stream) {
+    Q3_REQUIRE(mel && chunk_b && chunk_f0 && w9 && bias && out, "conv1_gelu: null pointer");
+    Q3_REQUIRE(n_chunks > 0 && Fmax > 0 && C1 > 0 && C1 % 8 == 0 && C1 <= 1024, "conv1_gelu: bad sizes (n_chunks=%d C1=%d)", n_chunks, C1);
+    const size_t lds = sizeof(float) * (3 * 130 + 10 * C1);
+    hipLaunchKernelGGL(conv1_gelu_kernel, dim3(50, n_chunks), dim3(256), lds, (hipStream_t)stream, mel, Fmax, chunk_b,
+                       chunk_f0, w9, bias, (bf16*)out, C1);
+    return q3_check_launch("conv1_gelu");
+}
+
+// ---------------------------------------------------------------------------
+// prepare_inputs (generate.py:20-81): out[m] = audio_src[m] >= 0 ? bf16(enc[audio_src[m]]) : E[ids[m]].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_merge_kernel(const int* __restrict__ ids, const int* __restrict__ audio_src,
+                                                          const bf16* __restrict__ E, const float* __restrict__ enc,
+                                                          bf16* __restrict__ out, int H) {
+    const long m = blockIdx.x;
+    const int a = audio_src[m];
+    bf16* o = out + m * H;
+    if (a >= 0) {
+        const float* src = enc + (long)a * H;
+        for (int i = threadIdx.x * 4; i < H; i += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+            bf16x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = f2bf(v[e]);
+            *reinterpret_cast<bf16x4*>(o + i) = r;
+        }
+    } else {
+        const bf16* src = E + (long)ids[m] * H;
+        for (int i = threadIdx.x * 8; i < H; i += 2048)
+            *reinterpret_cast<uint4*>(o + i) = *reinterpret_cast<const uint4*>(src + i);
+    }
+}
+
+extern "C" int q3asr_embed_merge(const int32_t* ids, const int32_t* audio_src, const void* E, const float* enc, void* out,
+                                 int M, int H, void* stream) {
+    Q3_REQUIRE(ids && audio_src && E && out, "embed_merge: null pointer");
+    Q3_REQUIRE(M > 0 && H % 8 == 0, "embed_merge: M=%d H=%d", M, H);
+    hipLaunchKernelGGL(embed_merge_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, ids, audio_src, (const bf16*)E, enc,
+                       (bf16*)out, H);
+    return q3_check_launch("embed_merge");
+}
+
+// ---------------------------------------------------------------------------
+// Per-head q/k RMSNorm(128) -> RoPE (half-split pairs (i, i+64), base theta) -> q out,
+// k/v appended in place to the KV cache (decoder.py:140-156, KVCache.update :32-64 made
+// O(1)).  One wave per (token row, head slot); lane i owns the rotation pair (i, i+64).
+// Input is either the bf16 qkv GEMM output or S fp32 split-K slabs (decode path), whose
+// sum is first rounded to bf16 (the q_proj output dtype).
+// cache layout: [B][n_kv][Lmax][128] bf16, K and V separately (one layer).
+// ---------------------------------------------------------------------------
+template <bool SLAB>
+__global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(const void* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
+                                                              const int* __restrict__ row_b, const int* __restrict__ row_pos,
+                                                              const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
+                                                              const float* __restrict__ inv_freq, float eps,
+                                                              bf16* __restrict__ q_out, bf16* __restrict__ k_cache,
+                                                              bf16* __restrict__ v_cache, int M, int nh, int nkv, int Lmax) {
+    const int slots = nh + 2 * nkv;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long)M * slots) return;
+    const int m = (int)(w / slots), hs = (int)(w - (long)m * slots);
+    const int lane = threadIdx.x & 63;
+    float x1, x2;
+    if (SLAB) {
+        const float* base = (const float*)qkv + (long)m * ld + hs * 128;
+        float a = 0.f, c = 0.f;
+        for (int s = 0; s < n_slabs; ++s) {
+            a += base[s * slab_stride + lane];
+            c += base[s * slab_stride + lane + 64];
+        }
+        x1 = round_bf(a);
+        x2 = round_bf(c);
+    } else {
+        const bf16* base = (const bf16*)qkv + (long)m * ld + hs * 128;
+        x1 = bf2f(base[lane]);
+        x2 = bf2f(base[lane + 64]);
+    }
+    const int b = row_b[m], pos = row_pos[m];
+    if (hs >= nh + nkv) {                                   // v: plain append
+        bf16* dst = v_cache + (((long)b * nkv + (hs - nh - nkv)) * Lmax + pos) * 128;
+        dst[lane] = f2bf(x1);
+        dst[lane + 64] = f2bf(x2);
+        return;
+    }
+    const bf16* nw = hs < nh ? qn_w : kn_w;
+    const float ss = wave_sum(x1 * x1 + x2 * x2) * (1.0f / 128.0f);
+    const float r = rsqrtf(ss + eps);
+    const float y1 = round_bf(x1 * r * bf2f(nw[lane]));
+    const float y2 = round_bf(x2 * r * bf2f(nw[lane + 64]));
+    const float ang = (float)pos * inv_freq[lane];
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    const bf16 o1 = f2bf(y1 * cs - y2 * sn);
+    const bf16 o2 = f2bf(y1 * sn + y2 * cs);
+    bf16* dst = hs < nh ? q_out + (long)m * nh * 128 + hs * 128
+                        : k_cache + (((long)b * nkv + (hs - nh)) * Lmax + pos) * 128;
+    dst[lane] = o1;
+    dst[lane + 64] = o2;
+}
+
+extern "C" int q3asr_qk_norm_rope_kv(const void* qkv, int is_slab, int64_t ld, int n_slabs, int64_t slab_stride,
+                                     const int32_t* row_b, const int32_t* row_pos, const void* qn_w, const void* kn_w,
+                                     const float* inv_freq, float eps, void* q_out, void* k_cache, void* v_cache, int M,
+                                     int nh, int nkv, int head_dim, int Lmax, void* stream) {
+    Q3_REQUIRE(qkv && row_b && row_pos && qn_w && kn_w && inv_freq && q_out && k_cache && v_cache, "qk_norm_rope_kv: null pointer");
+    Q3_REQUIRE(head_dim == 128, "qk_norm_rope_kv: head_dim=%d unsupported (128 only)", head_dim);
+    Q3_REQUIRE(M > 0 && nh > 0 && nkv > 0 && Lmax > 0 && ld >= (int64_t)(nh + 2 * nkv) * 128, "qk_norm_rope_kv: bad sizes");
+    const long waves = (long)M * (nh + 2 * nkv);
+    dim3 grid((unsigned)((waves + 3) / 4)), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (is_slab) {
+        Q3_REQUIRE(n_slabs > 0, "qk_norm_rope_kv: n_slabs=%d", n_slabs);
+        hipLaunchKernelGGL(qk_norm_rope_kv_kernel<true>, grid, blk, 0, s, qkv, (long)ld, n_slabs, (long)slab_stride, row_b, row_pos,
+                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)q_out, (bf16*)k_cache, (bf16*)v_cache, M, nh, nkv, Lmax);
+    } else {
+        hipLaunchKernelGGL(qk_norm_rope_kv_kernel<false>, grid, blk, 0, s, qkv, (long)ld, 0, 0L, row_b, row_pos,
+                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)q_out, (bf16*)k_cache, (bf16*)v_cache, M, nh, nkv, Lmax);
+    }
+    return q3_check_launch("qk_norm_rope_kv");
+}

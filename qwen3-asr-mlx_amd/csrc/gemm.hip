@@ -1,0 +1,265 @@
+// bf16 MFMA GEMM with fused epilogues:  C[M,N] = A[M,K] . W[N,K]^T
+//
+// Serves every MLX nn.Linear / nn.Conv2d call site on the large-M side of the
+// path (SURVEY.md K3,K4,K7,K11,K16,K17): encoder q/k/v/out/fc1/fc2/proj, the
+// conv stem as implicit GEMM (im2col addresses generated in the A loader, never
+// materialised), decoder prefill projections.  Both operands are K-contiguous
+// (activations row-major, weights in the checkpoint's (out,in) layout), so both
+// are staged the same way: 16-byte global loads -> registers -> XOR-swizzled LDS
+// tile [128 rows][64 bf16] -> ds_read_b128 fragments -> v_mfma_f32_16x16x32_bf16.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA
+// tiles.  The MFMA is issued "swapped" (A operand = weight fragment, B operand =
+// activation fragment), so a lane ends up with 4 consecutive output columns of
+// one row: bias/residual loads and the store are 8/16-byte vectors, and the
+// SwiGLU pair (gate, up) of a feature sits in the same lane and register.
+// Bound: MFMA (dense bf16 peak 2.5 PFLOP/s); algorithmic flops = 2*M*N*K.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define GROUP_M 8
+
+struct GemmParams {
+    const bf16* A; long lda;
+    const bf16* W; long ldw;
+    int M, N, K;
+    // implicit-GEMM conv (k3 s2 p1, NHWC): A = input [imgs][Hin][Win][Cin], M = imgs*Hout*Wout, K = 9*Cin
+    int Hin, Win, Cin, Hout, Wout;
+    const float* bias;
+    int act;                 // 0 none, 1 exact-erf GELU, 2 SwiGLU over 16-row interleaved (gate, up) weight rows
+    const void* res; int res_kind; long ldres; int res_mod;   // 0 none, 1 fp32, 2 bf16 (MLX bf16 add: round, add, round)
+    void* out; int out_kind; long ldo;                        // 0 bf16, 1 fp32
+    const int* row_map;      // optional destination row per m (<0: skip)
+};
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+template <int CONV>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * BM * BK * 2];   // A0 | W0 | A1 | W1, 16 KB each
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    const int group = GROUP_M * tiles_n;
+    const int first_m = (t / group) * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (int)(t % group) % gm;
+    const int tn = (int)(t % group) / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- loader state: this thread moves 4 A slots and 4 W slots (16 B each) per K tile
+    const int slot = tid & 7, lrow = tid >> 3;
+    long a_base[4];
+    int a_ih0[4], a_iw0[4];
+    bool a_ok[4], w_ok[4];
+    long w_base[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int am = m0 + lrow + 32 * q;
+        a_ok[q] = am < p.M;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int img = am / hw, rem = am - img * hw;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_ih0[q] = 2 * oh - 1;
+            a_iw0[q] = 2 * ow - 1;
+            a_base[q] = (long)img * p.Hin * p.Win * p.Cin;
+        } else {
+            a_base[q] = (long)am * p.lda;
+            a_ih0[q] = a_iw0[q] = 0;
+        }
+        const int wn_ = n0 + lrow + 32 * q;
+        w_ok[q] = wn_ < p.N;
+        w_base[q] = (long)wn_ * p.ldw;
+    }
+
+    uint4 ra[4], rw[4];
+    auto load_tile = [&](int k0) {
+        const int k = k0 + slot * 8;
+        const bool kin = k < p.K;
+        int tap_off = 0, kh = 0, kw = 0;
+        if (CONV) {
+            const int tap = k / p.Cin;
+            const int ci = k - tap * p.Cin;
+            kh = tap / 3;
+            kw = tap - 3 * kh;
+            tap_off = ci;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (CONV) {
+                const int ih = a_ih0[q] + kh, iw = a_iw0[q] + kw;
+                if (a_ok[q] && kin && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
+                    v = *reinterpret_cast<const uint4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + tap_off));
+            } else {
+                if (a_ok[q] && kin) v = *reinterpret_cast<const uint4*>(p.A + a_base[q] + k);
+            }
+            ra[q] = v;
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (w_ok[q] && kin) w = *reinterpret_cast<const uint4*>(p.W + w_base[q] + k);
+            rw[q] = w;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sa = smem + buf * (2 * BM * BK * 2);
+        char* sw = sa + BM * BK * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = lrow + 32 * q;
+            *reinterpret_cast<uint4*>(sa + lds_off(r, slot)) = ra[q];
+            *reinterpret_cast<uint4*>(sw + lds_off(r, slot)) = rw[q];
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    f32x4 acc[4][4];   // [j: n tile][i: m tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const char* sa = smem + buf * (2 * BM * BK * 2);
+        const char* sw = sa + BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[4], af[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[j] = *reinterpret_cast<const bf16x8*>(sw + lds_off(wn * 64 + j * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 64 + i * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, for tile (j,i): row m = .. + li, columns n = .. + 4g + r, r = 0..3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + li;
+        if (m >= p.M) continue;
+        long orow = m;
+        if (p.row_map) {
+            orow = p.row_map[m];
+            if (orow < 0) continue;
+        }
+        const long rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+        if (p.act == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int n_in = n0 + wn * 64 + j * 16 + 4 * g;      // gate rows; up rows are n_in + 16
+                if (n_in >= p.N) continue;
+                const int n_out = (n0 >> 1) + wn * 32 + (j >> 1) * 16 + 4 * g;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gt = round_bf(acc[j][i][r]);            // gate_proj output is bf16 (decoder.py:97)
+                    const float up = round_bf(acc[j + 1][i][r]);
+                    o[r] = f2bf(gt / (1.0f + __expf(-gt)) * up);
+                }
+                *reinterpret_cast<bf16x4*>((bf16*)p.out + orow * p.ldo + n_out) = o;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * g;
+            if (n >= p.N) continue;
+            f32x4 v = acc[j][i];
+            if (p.bias) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                v += bv;
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (p.res_kind == 1) {
+                v += *reinterpret_cast<const f32x4*>((const float*)p.res + rrow * p.ldres + n);
+            } else if (p.res_kind == 2) {
+                const bf16x4 rv = *reinterpret_cast<const bf16x4*>((const bf16*)p.res + rrow * p.ldres + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = round_bf(v[r]) + bf2f(rv[r]);
+            }
+            if (p.out_kind == 1) {
+                *reinterpret_cast<f32x4*>((float*)p.out + orow * p.ldo + n) = v;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+                *reinterpret_cast<bf16x4*>((bf16*)p.out + orow * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
+static int gemm_validate(const GemmParams& p, const char* who) {
+    Q3_REQUIRE(p.A && p.W && p.out, "%s: null pointer", who);
+    Q3_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "%s: M=%d N=%d K=%d must be positive", who, p.M, p.N, p.K);
+    Q3_REQUIRE(p.K % 8 == 0 && p.N % 4 == 0, "%s: K=%d must be a multiple of 8 and N=%d of 4", who, p.K, p.N);
+    Q3_REQUIRE(p.ldw % 8 == 0 && p.ldw >= p.K, "%s: ldw=%ld must be >= K and a multiple of 8", who, p.ldw);
+    Q3_REQUIRE(p.act >= 0 && p.act <= 2 && p.res_kind >= 0 && p.res_kind <= 2 && p.out_kind >= 0 && p.out_kind <= 1,
+               "%s: bad epilogue selector", who);
+    Q3_REQUIRE(p.res_kind == 0 || p.res, "%s: residual kind set without pointer", who);
+    if (p.act == 2) {
+        Q3_REQUIRE(p.N % 32 == 0 && p.out_kind == 0 && !p.bias && p.res_kind == 0,
+                   "%s: SwiGLU epilogue needs N%%32==0, bf16 out, no bias/residual", who);
+        Q3_REQUIRE(p.ldo % 4 == 0 && p.ldo >= p.N / 2, "%s: ldo=%ld too small for SwiGLU output", who, p.ldo);
+    } else {
+        Q3_REQUIRE(p.ldo % 4 == 0 && p.ldo >= p.N, "%s: ldo=%ld must be >= N and a multiple of 4", who, p.ldo);
+    }
+    Q3_REQUIRE(p.res_kind == 0 || (p.ldres % 4 == 0 && p.ldres >= p.N), "%s: bad ldres=%ld", who, p.ldres);
+    return Q3_OK;
+}
+
+extern "C" int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
+                               const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
+                               void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream) {
+    GemmParams p{};
+    p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.act = act; p.res = res; p.res_kind = res_kind; p.ldres = ldres; p.res_mod = res_mod;
+    p.out = out; p.out_kind = out_kind; p.ldo = ldo; p.row_map = row_map;
+    if (int rc = gemm_validate(p, "gemm_bf16")) return rc;
+    Q3_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_bf16: lda=%ld must be >= K and a multiple of 8", (long)lda);
+    const unsigned tiles = (unsigned)((M + BM - 1) / BM) * (unsigned)((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return q3_check_launch("gemm_bf16");
+}
+
+// Conv2d k3 s2 p1 over NHWC bf16 as implicit GEMM (encoder.py:155-168,274-275).
+// x [imgs][Hin][Win][Cin]; w [Cout][3][3][Cin] (tap order follows x's two spatial dims);
+// out row m = (img*Hout + oh)*Wout + ow, or row_map[m].
+extern "C" int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, int Cin, const void* w, int Cout,
+                                    const float* bias, int act, void* out, int out_kind, int64_t ldo,
+                                    const int32_t* row_map, void* stream) {
+    GemmParams p{};
+    p.A = (const bf16*)x; p.lda = 0; p.W = (const bf16*)w; p.ldw = 9L * Cin;
+    p.Hin = Hin; p.Win = Win; p.Cin = Cin;
+    p.Hout = (Hin - 1) / 2 + 1; p.Wout = (Win - 1) / 2 + 1;
+    p.M = imgs * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin;
+    p.bias = bias; p.act = act; p.out = out; p.out_kind = out_kind; p.ldo = ldo; p.row_map = row_map;
+    Q3_REQUIRE(imgs > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cin % 8 == 0, "conv3x3s2: bad geometry (Cin=%d must be a multiple of 8)", Cin);
+    Q3_REQUIRE((long)imgs * p.Hout * p.Wout < 2147483647L, "conv3x3s2: M overflows int32");
+    if (int rc = gemm_validate(p, "conv3x3s2")) return rc;
+    Q3_REQUIRE(act != 2, "conv3x3s2: SwiGLU epilogue not valid here");
+    const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return q3_check_launch("conv3x3s2");
+}

@@ -1,0 +1,392 @@
+"""Qwen3 text decoder on HIP kernels (mirror of reference decoder.py; same class / loader names).
+
+Two regimes: *prefill* (MFMA-bound, all prompt rows of all sequences packed into one matrix) and
+*decode* (HBM-bound, one row per sequence, weight-streaming skinny GEMMs with split-K slabs,
+captured into a hipGraph).  bf16 everywhere an MLX op would produce bf16; fp32 accumulation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional, Sequence
+
+from . import _lib, ops
+from .config import TextDecoderConfig
+from .tokenizer import ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID
+
+
+class KVCache:
+    """Pre-allocated per-layer key/value cache (the reference grows by concatenation,
+    decoder.py:20-64).  ``offset`` is maintained by the caller exactly as in the reference
+    (generate.py:275,298).  Buffers: k, v bf16 [layers][B][n_kv][Lmax][head_dim]."""
+
+    def __init__(self) -> None:
+        self.offset: int = 0
+        self.k = None
+        self.v = None
+        self.batch = 0
+        self.max_len = 0
+
+    def ensure(self, cfg: TextDecoderConfig, batch: int, max_len: int, device) -> None:
+        import torch
+        if self.k is None or batch != self.batch or max_len > self.max_len:
+            old = (self.k, self.v, self.max_len)
+            shape = (cfg.num_hidden_layers, batch, cfg.num_key_value_heads, max_len, cfg.head_dim)
+            self.k = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+            self.v = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+            if old[0] is not None and batch == self.batch and self.offset > 0:      # grow: keep contents
+                self.k[:, :, :, : old[2]] = old[0]
+                self.v[:, :, :, : old[2]] = old[1]
+            self.batch, self.max_len = batch, max_len
+
+    @property
+    def keys(self):
+        return [] if self.k is None else [self.k[i, :, :, : self.offset] for i in range(self.k.shape[0])]
+
+    @property
+    def values(self):
+        return [] if self.v is None else [self.v[i, :, :, : self.offset] for i in range(self.v.shape[0])]
+
+
+def create_additive_causal_mask(N: int, offset: int = 0):
+    """(N, offset+N) additive mask, -1e9 above the diagonal (reference decoder.py:71-80).  The HIP
+    attention kernels apply causality by index; kept for API parity."""
+    import torch
+    r = torch.arange(offset + N)
+    l = torch.arange(offset, offset + N)
+    return (l[:, None] < r[None]).to(torch.float32) * -1e9
+
+
+class _Embedding:
+    def __init__(self, weight):
+        self.weight = weight
+
+    def __call__(self, ids):
+        import torch
+        return self.weight[torch.as_tensor(ids, device=self.weight.device, dtype=torch.long)]
+
+
+class DecodeWorkspace:
+    """Device state of one decode batch; pointers are stable so one hipGraph serves every step."""
+
+    def __init__(self, cfg: TextDecoderConfig, B: int, max_out: int, device):
+        import torch
+        i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=device)          # noqa: E731
+        bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=device)        # noqa: E731
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        qd = cfg.num_attention_heads * cfg.head_dim
+        qkvd = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim
+        self.B, self.max_out = B, max_out
+        self.cur_tok, self.pos, self.n_gen, self.finished, self.max_new = i32(B), i32(B), i32(B), i32(B), i32(B)
+        self.row_b = torch.arange(B, dtype=torch.int32, device=device)
+        self.out_tokens = i32(B, max_out)
+        self.h, self.x, self.q, self.att, self.act = bf(B, H), bf(B, H), bf(B, qd), bf(B, qd), bf(B, I)
+        self.logits = bf(B, cfg.vocab_size)
+        self.splits = {
+            "qkv": ops.pick_splits(qkvd, H), "o": ops.pick_splits(H, qd),
+            "gu": ops.pick_splits(2 * I, H), "down": ops.pick_splits(H, I),
+        }
+        n_slab = max(self.splits["qkv"] * qkvd, self.splits["o"] * H, self.splits["gu"] * 2 * I, self.splits["down"] * H)
+        self.slab = torch.empty((n_slab * B,), dtype=torch.float32, device=device)
+        self.graph = None
+        self.graph_key = None
+
+    def __del__(self):
+        if getattr(self, "graph", None):
+            try:
+                _lib.load().q3asr_graph_destroy(self.graph)
+            except Exception:
+                pass
+
+
+class TextDecoder:
+    def __init__(self, config: TextDecoderConfig) -> None:
+        self.config = config
+        if config.head_dim != 128 or config.num_attention_heads != 2 * config.num_key_value_heads:
+            raise NotImplementedError("HIP decoder kernels are specialised for head_dim 128 and GQA 2:1")
+        self.w = None
+        self.device = None
+        self.embed_tokens = None
+        self._plans: dict = {}
+        self._ws: dict = {}
+        self._caches: dict = {}
+        self._api_ws = None
+
+    # ------------------------------------------------------------------ weights
+    def load_state(self, W: dict, device) -> None:
+        """W: checkpoint tensors with the ``model.`` prefix stripped (reference decoder.py:282-290).
+        Strict key set.  The lm_head is tied to embed_tokens (decoder.py:252)."""
+        import torch
+        cfg = self.config
+        dev = torch.device(device)
+        need = {"embed_tokens.weight", "norm.weight"}
+        names = ("input_layernorm.weight", "post_attention_layernorm.weight", "self_attn.q_proj.weight",
+                 "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                 "self_attn.q_norm.weight", "self_attn.k_norm.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
+                 "mlp.down_proj.weight")
+        for i in range(cfg.num_hidden_layers):
+            need.update(f"layers.{i}.{n}" for n in names)
+        missing, extra = need - set(W), set(W) - need
+        if missing or extra:
+            raise ValueError(f"decoder weights: missing {sorted(missing)[:4]} extra {sorted(extra)[:4]}")
+
+        def bf(t):
+            return t.to(device=dev, dtype=torch.bfloat16).contiguous()
+
+        I = cfg.intermediate_size
+        w = {"embed": bf(W["embed_tokens.weight"]), "norm": bf(W["norm.weight"]), "layers": []}
+        for i in range(cfg.num_hidden_layers):
+            p = f"layers.{i}."
+            gate, up = W[p + "mlp.gate_proj.weight"].to(dev), W[p + "mlp.up_proj.weight"].to(dev)
+            gu = torch.stack([gate.reshape(I // 16, 16, -1), up.reshape(I // 16, 16, -1)], dim=1).reshape(2 * I, -1)
+            w["layers"].append({
+                "ln1": bf(W[p + "input_layernorm.weight"]), "ln2": bf(W[p + "post_attention_layernorm.weight"]),
+                "wqkv": bf(torch.cat([W[p + "self_attn.q_proj.weight"], W[p + "self_attn.k_proj.weight"],
+                                      W[p + "self_attn.v_proj.weight"]], 0)),
+                "wo": bf(W[p + "self_attn.o_proj.weight"]),
+                "qn": bf(W[p + "self_attn.q_norm.weight"]), "kn": bf(W[p + "self_attn.k_norm.weight"]),
+                "wgu": bf(gu), "wdown": bf(W[p + "mlp.down_proj.weight"]),
+            })
+        half = cfg.head_dim // 2
+        # MLX nn.RoPE(traditional=False): angle = pos * base**(-i/half) (decoder.py:126)
+        w["inv_freq"] = (float(cfg.rope_theta) ** (-torch.arange(half, dtype=torch.float32) / half)).to(dev)
+        self.w, self.device = w, dev
+        self.embed_tokens = _Embedding(w["embed"])
+
+    # ------------------------------------------------------------------ prefill (hot path)
+    def _prefill_plan(self, seq_lens: tuple, Lmax: int):
+        key = (seq_lens, Lmax)
+        pl = self._plans.get(key)
+        if pl is None:
+            import torch
+            cfg, dev = self.config, self.device
+            row_b, row_pos, starts, last = [], [], [], []
+            m = 0
+            for b, t in enumerate(seq_lens):
+                starts.append(m)
+                row_b += [b] * t
+                row_pos += list(range(t))
+                m += t
+                last.append(m - 1)
+            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
+            pl = {"row_b": i32(row_b), "row_pos": i32(row_pos), "seg_start": i32(starts), "seg_len": i32(list(seq_lens)),
+                  "last": i32(last), "M": m, "max_len": max(seq_lens),
+                  "kv_off": torch.tensor([b * cfg.num_key_value_heads * Lmax * cfg.head_dim for b in range(len(seq_lens))],
+                                         dtype=torch.int64, device=dev)}
+            if len(self._plans) > 64:
+                self._plans.clear()
+            self._plans[key] = pl
+        return pl
+
+    def _layers_prefill(self, h, cache: KVCache, seq_lens: Sequence[int]):
+        """h bf16 [M][H] (packed rows of all sequences, positions start at 0) -> updated in place."""
+        import torch
+        cfg, w, dev = self.config, self.w, self.device
+        pl = self._prefill_plan(tuple(int(t) for t in seq_lens), cache.max_len)
+        M, H, I = pl["M"], cfg.hidden_size, cfg.intermediate_size
+        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
+        bf16 = torch.bfloat16
+        x = torch.empty((M, H), dtype=bf16, device=dev)
+        qkv = torch.empty((M, qkvd), dtype=bf16, device=dev)
+        q = torch.empty((M, qd), dtype=bf16, device=dev)
+        att = torch.empty((M, qd), dtype=bf16, device=dev)
+        act = torch.empty((M, I), dtype=bf16, device=dev)
+        eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
+        for li, L in enumerate(w["layers"]):
+            ops.rmsnorm(h, L["ln1"], x, M, H, eps)
+            ops.gemm(x, L["wqkv"], M, qkvd, H, qkv)
+            ops.call("q3asr_qk_norm_rope_kv", ops.ptr(qkv), 0, qkvd, 0, 0, ops.ptr(pl["row_b"]), ops.ptr(pl["row_pos"]),
+                     ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(q), ops.ptr(cache.k[li]),
+                     ops.ptr(cache.v[li]), M, nh, nkv, hd, Lmax, ops.sp())
+            ops.attn_fwd(ops.ptr(q), qd, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), pl["kv_off"], Lmax * hd, hd, att, qd,
+                         pl["seg_start"], pl["seg_len"], len(seq_lens), pl["max_len"], nh, nkv, hd, True, scale)
+            ops.gemm(att, L["wo"], M, H, qd, h, res=h, res_kind=2, ldres=H)
+            ops.rmsnorm(h, L["ln2"], x, M, H, eps)
+            ops.gemm(x, L["wgu"], M, 2 * I, H, act, act=2)
+            ops.gemm(act, L["wdown"], M, H, I, h, res=h, res_kind=2, ldres=H)
+        return pl
+
+    def prefill(self, embeds, seq_lens: Sequence[int], cache: KVCache, logits_out=None):
+        """Packed prompt embeddings bf16 [sum T_b][H] -> bf16 logits of each sequence's LAST
+        position [B][V] (the reference computes all T rows, decoder.py:251-252, and consumes only the
+        last, generate.py:279).  Fills cache positions 0..T_b-1."""
+        import torch
+        cfg, w = self.config, self.w
+        B = len(seq_lens)
+        h = embeds.clone()
+        pl = self._layers_prefill(h, cache, seq_lens)
+        xl = torch.empty((B, cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
+        ops.rmsnorm(h, w["norm"], xl, B, cfg.hidden_size, cfg.rms_norm_eps, row_idx=pl["last"])
+        if logits_out is None:
+            logits_out = torch.empty((B, cfg.vocab_size), dtype=torch.bfloat16, device=self.device)
+        self._lm_head(xl, B, logits_out)
+        return logits_out
+
+    def _lm_head(self, x, M, out):
+        cfg = self.config
+        for m0 in range(0, M, 64):
+            mm = min(64, M - m0)
+            ops.skinny_gemm(x[m0:], mm, self.w["embed"], cfg.vocab_size, cfg.hidden_size, 1, None, out[m0:])
+
+    # ------------------------------------------------------------------ decode step (hot path)
+    def workspace(self, B: int, max_out: int) -> DecodeWorkspace:
+        key = (B, max_out)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 8:
+                self._ws.clear()
+            ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device)
+        return ws
+
+    def batch_cache(self, B: int, Lmax: int) -> KVCache:
+        """Decoder-owned cache with stable device pointers (so a captured decode graph stays valid
+        across calls with the same batch geometry)."""
+        key = (B, Lmax)
+        c = self._caches.get(key)
+        if c is None:
+            if len(self._caches) > 2:
+                self._caches.clear()
+            c = self._caches[key] = KVCache()
+            c.ensure(self.config, B, Lmax, self.device)
+        c.offset = 0
+        return c
+
+    def decode_step(self, ws: DecodeWorkspace, cache: KVCache, sampling: dict) -> None:
+        """One token for every sequence: embed(cur_tok) -> 28 layers at position pos[b] -> tied head ->
+        sample -> bookkeeping.  ~9 launches per layer, no host interaction (graph-capturable)."""
+        cfg, w = self.config, self.w
+        B, H, I = ws.B, cfg.hidden_size, cfg.intermediate_size
+        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
+        eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
+        sp = ws.splits
+        layers = w["layers"]
+        ops.call("q3asr_embed_rmsnorm", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
+                 ops.ptr(ws.x), B, H, eps, ops.sp())
+        for li, L in enumerate(layers):
+            self._skinny_slab(ws.x, B, L["wqkv"], qkvd, H, sp["qkv"], ws.slab)
+            ops.call("q3asr_qk_norm_rope_kv", ops.ptr(ws.slab), 1, qkvd, sp["qkv"], B * qkvd, ops.ptr(ws.row_b), ops.ptr(ws.pos),
+                     ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(ws.q), ops.ptr(cache.k[li]),
+                     ops.ptr(cache.v[li]), B, nh, nkv, hd, Lmax, ops.sp())
+            ops.call("q3asr_attn_decode", ops.ptr(ws.q), ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(ws.pos),
+                     ops.ptr(ws.att), B, nh, nkv, hd, Lmax, scale, ops.sp())
+            self._skinny_slab(ws.att, B, L["wo"], H, qd, sp["o"], ws.slab)
+            ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(ws.slab), sp["o"], B * H, ops.ptr(ws.h), ops.ptr(ws.h),
+                     ops.ptr(L["ln2"]), ops.ptr(ws.x), B, H, eps, ops.sp())
+            self._skinny_slab(ws.x, B, L["wgu"], 2 * I, H, sp["gu"], ws.slab)
+            ops.call("q3asr_slab_swiglu", ops.ptr(ws.slab), sp["gu"], B * 2 * I, ops.ptr(ws.act), B, I, ops.sp())
+            self._skinny_slab(ws.act, B, L["wdown"], H, I, sp["down"], ws.slab)
+            nxt = layers[li + 1]["ln1"] if li + 1 < len(layers) else w["norm"]
+            ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(ws.slab), sp["down"], B * H, ops.ptr(ws.h), ops.ptr(ws.h),
+                     ops.ptr(nxt), ops.ptr(ws.x), B, H, eps, ops.sp())
+        ops.skinny_gemm(ws.x, B, w["embed"], cfg.vocab_size, H, 1, None, ws.logits)
+        self.sample_step(ws, ws.logits, sampling)
+
+    def _skinny_slab(self, X, M, W, N, K, splits, slab):
+        # always through the slab (splits may be 1): the consumer kernels read fp32 partials
+        ops.call("q3asr_skinny_gemm", ops.ptr(X), K, M, ops.ptr(W), K, N, K, splits, ops.ptr(slab), None, N, ops.sp())
+
+    def sample_step(self, ws: DecodeWorkspace, logits, s: dict) -> None:
+        ops.call("q3asr_sample_step", ops.ptr(logits), logits.stride(0), ws.B, self.config.vocab_size, ops.ptr(ws.out_tokens),
+                 ws.max_out, ops.ptr(ws.n_gen), ops.ptr(ws.finished), ops.ptr(ws.cur_tok), ops.ptr(ws.pos), ops.ptr(ws.max_new),
+                 float(s["temperature"]), float(s["top_p"]), int(s["top_k"]), float(s["repetition_penalty"]),
+                 int(s["repetition_context_size"]), int(s.get("seed", 0)), ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID, ops.sp())
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture_step(self, ws: DecodeWorkspace, cache: KVCache, sampling: dict) -> None:
+        import torch
+        key = (id(cache.k), cache.max_len, tuple(sorted(sampling.items())))
+        if ws.graph is not None and ws.graph_key == key:
+            return
+        if ws.graph is not None:
+            _lib.call("q3asr_graph_destroy", ws.graph)
+            ws.graph = None
+        stream = torch.cuda.current_stream()
+        _lib.call("q3asr_graph_begin", C.c_void_p(stream.cuda_stream))
+        try:
+            self.decode_step(ws, cache, sampling)
+        finally:
+            g = C.c_void_p()
+            _lib.call("q3asr_graph_end", C.c_void_p(stream.cuda_stream), C.byref(g))
+        ws.graph, ws.graph_key = g, key
+
+    def replay_step(self, ws: DecodeWorkspace) -> None:
+        import torch
+        _lib.call("q3asr_graph_launch", ws.graph, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    # ------------------------------------------------------------------ reference-shaped call (batch 1)
+    def __call__(self, inputs, cache: Optional[KVCache] = None, is_embeds: bool = False):
+        """Token ids (1,T) or embeddings (1,T,H) -> bf16 logits (1,T,V) for EVERY position, appending
+        to ``cache`` at ``cache.offset`` (reference decoder.py:219-253; the caller advances offset)."""
+        import torch
+        if self.w is None:
+            raise TypeError("TextDecoder has no weights loaded")
+        cfg, w, dev = self.config, self.w, self.device
+        t = torch.as_tensor(inputs) if not isinstance(inputs, torch.Tensor) else inputs
+        h = (t.to(dev, torch.bfloat16) if is_embeds else self.embed_tokens(t.to(dev)))
+        if h.ndim == 3:
+            if h.shape[0] != 1:
+                raise NotImplementedError("reference-shaped call is batch 1; use prefill()/generate_batch for batches")
+            h = h[0]
+        h = h.contiguous().clone()
+        T = h.shape[0]
+        cache = cache if cache is not None else KVCache()
+        off = cache.offset
+        if off + T > cache.max_len or cache.batch != 1:
+            cache.ensure(cfg, 1, max(off + T, 2 * cache.max_len, 64), dev)
+        if off == 0:
+            self._layers_prefill(h, cache, [T])
+            x = torch.empty_like(h)
+            ops.rmsnorm(h, w["norm"], x, T, cfg.hidden_size, cfg.rms_norm_eps)
+        elif T == 1:
+            x = self._single_step_hidden(h, cache, off)
+        else:
+            raise NotImplementedError("multi-token call with a non-empty cache")
+        logits = torch.empty((T, cfg.vocab_size), dtype=torch.bfloat16, device=dev)
+        if T <= 64:
+            self._lm_head(x, T, logits)
+        else:
+            ops.gemm(x, w["embed"], T, cfg.vocab_size, cfg.hidden_size, logits)
+        return logits[None]
+
+    def _single_step_hidden(self, h, cache: KVCache, off: int):
+        """One token at position `off` through the decode kernels; returns the final-norm output."""
+        import torch
+        cfg, w = self.config, self.w
+        ws = self._api_ws
+        if ws is None:
+            ws = self._api_ws = DecodeWorkspace(cfg, 1, 1, self.device)
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
+        eps, scale, Lmax, sp = cfg.rms_norm_eps, hd ** -0.5, cache.max_len, ws.splits
+        ws.pos.fill_(off)
+        ws.h.copy_(h)
+        ops.rmsnorm(ws.h, w["layers"][0]["ln1"], ws.x, 1, H, eps)
+        layers = w["layers"]
+        for li, L in enumerate(layers):
+            self._skinny_slab(ws.x, 1, L["wqkv"], qkvd, H, sp["qkv"], ws.slab)
+            ops.call("q3asr_qk_norm_rope_kv", ops.ptr(ws.slab), 1, qkvd, sp["qkv"], qkvd, ops.ptr(ws.row_b), ops.ptr(ws.pos),
+                     ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(ws.q), ops.ptr(cache.k[li]),
+                     ops.ptr(cache.v[li]), 1, nh, nkv, hd, Lmax, ops.sp())
+            ops.call("q3asr_attn_decode", ops.ptr(ws.q), ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(ws.pos),
+                     ops.ptr(ws.att), 1, nh, nkv, hd, Lmax, scale, ops.sp())
+            self._skinny_slab(ws.att, 1, L["wo"], H, qd, sp["o"], ws.slab)
+            ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(ws.slab), sp["o"], H, ops.ptr(ws.h), ops.ptr(ws.h),
+                     ops.ptr(L["ln2"]), ops.ptr(ws.x), 1, H, eps, ops.sp())
+            self._skinny_slab(ws.x, 1, L["wgu"], 2 * I, H, sp["gu"], ws.slab)
+            ops.call("q3asr_slab_swiglu", ops.ptr(ws.slab), sp["gu"], 2 * I, ops.ptr(ws.act), 1, I, ops.sp())
+            self._skinny_slab(ws.act, 1, L["wdown"], H, I, sp["down"], ws.slab)
+            nxt = layers[li + 1]["ln1"] if li + 1 < len(layers) else w["norm"]
+            ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(ws.slab), sp["down"], H, ops.ptr(ws.h), ops.ptr(ws.h),
+                     ops.ptr(nxt), ops.ptr(ws.x), 1, H, eps, ops.sp())
+        return ws.x.clone()
+
+
+def load_decoder_weights(decoder: TextDecoder, model_path: str | Path, device: Optional[str] = None) -> None:
+    """Load ``model.*`` from model.safetensors (reference decoder.py:260-291)."""
+    import torch
+    from .encoder import _read_safetensors
+    dev = device or f"cuda:{torch.cuda.current_device()}"
+    decoder.load_state(_read_safetensors(model_path, "model."), dev)

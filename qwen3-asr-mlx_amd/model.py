@@ -1,0 +1,253 @@
+"""High-level API (mirror of reference model.py): Qwen3ASR.from_pretrained / transcribe /
+warm_up / close, plus transcribe_batch (new: the reference is batch-1 and single-GPU)."""
+from __future__ import annotations
+
+import gc
+import threading
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .audio import get_frontend, load_audio, pack_audio
+from .config import ModelConfig
+from .decoder import TextDecoder, load_decoder_weights
+from .encoder import AudioEncoder, load_encoder_weights
+from .generate import generate_batch, _next_seed
+from .tokenizer import EOS_TOKEN_IDS, Tokenizer
+
+# ISO 639-1 -> language name used in the prompt (data table of reference model.py:28-96)
+LANGUAGE_MAP: dict[str, str] = dict(
+    af="Afrikaans", ar="Arabic", az="Azerbaijani", be="Belarusian", bg="Bulgarian", bn="Bengali", bs="Bosnian",
+    ca="Catalan", cs="Czech", cy="Welsh", da="Danish", de="German", el="Greek", en="English", es="Spanish",
+    et="Estonian", fa="Persian", fi="Finnish", fr="French", gl="Galician", gu="Gujarati", he="Hebrew", hi="Hindi",
+    hr="Croatian", hu="Hungarian", hy="Armenian", id="Indonesian", it="Italian", ja="Japanese", ka="Georgian",
+    kk="Kazakh", kn="Kannada", ko="Korean", lt="Lithuanian", lv="Latvian", mk="Macedonian", ml="Malayalam",
+    mn="Mongolian", mr="Marathi", ms="Malay", my="Burmese", ne="Nepali", nl="Dutch", no="Norwegian", pa="Punjabi",
+    pl="Polish", pt="Portuguese", ro="Romanian", ru="Russian", si="Sinhala", sk="Slovak", sl="Slovenian",
+    sq="Albanian", sr="Serbian", sv="Swedish", sw="Swahili", ta="Tamil", te="Telugu", th="Thai", tl="Filipino",
+    tr="Turkish", uk="Ukrainian", ur="Urdu", uz="Uzbek", vi="Vietnamese", zh="Chinese",
+)
+LANGUAGE_MAP["is"] = "Icelandic"     # `is` is a keyword, cannot be a dict() kwarg
+
+
+@dataclass
+class TranscriptionResult:
+    text: str
+    language: str
+    duration: float
+
+
+def _find_split_points(samples: np.ndarray, chunk_samples: int, search_samples: int, frame_samples: int = 480) -> list[int]:
+    """Low-energy split points for long audio (reference model.py:454-513): RMS of 480-sample
+    frames (tail dropped); for every boundary k*chunk_samples the first minimum within
+    +-search_samples, snapped to the frame start."""
+    total = len(samples)
+    n_frames = total // frame_samples
+    if n_frames == 0:
+        return []
+    frames = np.asarray(samples[: n_frames * frame_samples], dtype=np.float32).reshape(n_frames, frame_samples)
+    energy = np.sqrt(np.mean(frames ** 2, axis=1)).astype(np.float32)
+    radius = search_samples // frame_samples
+    points: list[int] = []
+    for boundary in range(chunk_samples, total, chunk_samples):
+        centre = boundary // frame_samples
+        lo, hi = max(0, centre - radius), min(n_frames - 1, centre + radius)
+        if lo >= hi:
+            points.append(boundary)
+        else:
+            points.append((int(np.argmin(energy[lo: hi + 1])) + lo) * frame_samples)
+    return points
+
+
+class Qwen3ASR:
+    """Qwen3-ASR speech-to-text on one MI355X (reference model.py:121-447)."""
+
+    MAX_BATCH = 64
+
+    def __init__(self, config: ModelConfig, encoder: AudioEncoder, decoder: TextDecoder, tokenizer: Tokenizer) -> None:
+        self._config = config
+        self._encoder = encoder
+        self._decoder = decoder
+        self._tokenizer = tokenizer
+        self._lock = threading.Lock()
+        self.use_graph = True
+
+    @classmethod
+    def from_pretrained(cls, model_id_or_path: str | Path, **kwargs) -> "Qwen3ASR":
+        """Local model directory (config.json, model.safetensors, tokenizer files) or a Hub repo id
+        (downloaded with snapshot_download(**kwargs); needs network).  Extra keyword ``device``."""
+        device = kwargs.pop("device", None)
+        path = Path(model_id_or_path)
+        if not path.is_dir():
+            from huggingface_hub import snapshot_download
+            path = Path(snapshot_download(repo_id=str(model_id_or_path), **kwargs))
+        config = ModelConfig.from_pretrained(path)
+        encoder = AudioEncoder(config.audio_encoder)
+        load_encoder_weights(encoder, path, device)
+        decoder = TextDecoder(config.text_decoder)
+        load_decoder_weights(decoder, path, device)
+        return cls(config, encoder, decoder, Tokenizer(path))
+
+    @classmethod
+    def from_state_dict(cls, config: ModelConfig, state: dict, tokenizer, device=None) -> "Qwen3ASR":
+        """Build from in-memory checkpoint tensors (keys as in model.safetensors)."""
+        import torch
+        dev = device or f"cuda:{torch.cuda.current_device()}"
+        encoder = AudioEncoder(config.audio_encoder)
+        encoder.load_state({k[len("audio_tower."):]: v for k, v in state.items() if k.startswith("audio_tower.")}, dev)
+        decoder = TextDecoder(config.text_decoder)
+        decoder.load_state({k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}, dev)
+        return cls(config, encoder, decoder, tokenizer)
+
+    # ------------------------------------------------------------------ public API
+    def transcribe(self, audio, language: Optional[str] = None, temperature: float = 0.0, top_p: float = 1.0,
+                   top_k: int = 0, repetition_penalty: float = 1.2, max_tokens: Optional[int] = None,
+                   repetition_context_size: int = 100, chunk_duration: float = 1200.0) -> TranscriptionResult:
+        with self._lock:
+            return self._transcribe_impl(audio, language, temperature, top_p, top_k, repetition_penalty, max_tokens,
+                                         repetition_context_size, chunk_duration)
+
+    def transcribe_batch(self, audios: Sequence, language: Optional[str] = None, temperature: float = 0.0,
+                         top_p: float = 1.0, top_k: int = 0, repetition_penalty: float = 1.2,
+                         max_tokens: Optional[int] = None, repetition_context_size: int = 100,
+                         chunk_duration: float = 1200.0) -> list[TranscriptionResult]:
+        """Transcribe many utterances together; element i equals ``transcribe(audios[i], ...)``."""
+        with self._lock:
+            samples = [self._as_samples(a) for a in audios]
+            lang = self._resolve_language(language)
+            results: list[Optional[TranscriptionResult]] = [None] * len(samples)
+            jobs = []                                            # (result index, segment samples, max_tokens)
+            seg_of: dict[int, list[int]] = {}
+            for i, s in enumerate(samples):
+                if len(s) == 0:
+                    results[i] = TranscriptionResult(text="", language="Unknown", duration=0.0)
+                    continue
+                dur = len(s) / 16_000
+                if dur > chunk_duration:                         # model.py:313,382-447
+                    cs = int(chunk_duration * 16_000)
+                    pts = _find_split_points(s, cs, int(5.0 * 16_000))
+                    prev = 0
+                    for sp in pts + [len(s)]:
+                        seg = s[prev:sp]
+                        prev = sp
+                        if len(seg) == 0:
+                            continue
+                        seg_of.setdefault(i, []).append(len(jobs))
+                        jobs.append((i, seg, max(256, int(len(seg) / 16_000 * 50))))
+                else:
+                    mt = max_tokens if max_tokens is not None else max(256, int(dur * 50))
+                    seg_of[i] = [len(jobs)]
+                    jobs.append((i, s, mt))
+            texts = self._run_jobs(jobs, lang, temperature, top_p, top_k, repetition_penalty, repetition_context_size)
+            for i, idxs in seg_of.items():
+                dur = len(samples[i]) / 16_000
+                if dur > chunk_duration:
+                    text = " ".join(t for t in (texts[j] for j in idxs) if t)
+                else:
+                    text = texts[idxs[0]]
+                results[i] = TranscriptionResult(text=text, language=lang, duration=dur)
+            return results  # type: ignore[return-value]
+
+    def warm_up(self) -> None:
+        """Load code objects / build plans with a 0.5 s dummy inference (reference model.py:252-259)."""
+        self.transcribe(np.zeros(8000, dtype=np.float32))
+
+    def close(self) -> None:
+        """Release weights (reference model.py:261-269)."""
+        self._encoder = None  # type: ignore[assignment]
+        self._decoder = None  # type: ignore[assignment]
+        gc.collect()
+        try:
+            import torch
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+
+    def __enter__(self) -> "Qwen3ASR":
+        return self
+
+    def __exit__(self, *args) -> None:
+        self.close()
+
+    # ------------------------------------------------------------------ internals
+    @staticmethod
+    def _as_samples(audio) -> np.ndarray:
+        if isinstance(audio, (str, Path)):
+            return load_audio(audio)
+        samples = np.asarray(audio, dtype=np.float32)
+        if samples.ndim != 1:
+            raise ValueError(f"Audio array must be 1-D (mono), got shape {samples.shape}")
+        return samples
+
+    def _transcribe_impl(self, audio, language, temperature, top_p, top_k, repetition_penalty, max_tokens,
+                         repetition_context_size, chunk_duration) -> TranscriptionResult:
+        samples = self._as_samples(audio)
+        if len(samples) == 0:
+            return TranscriptionResult(text="", language="Unknown", duration=0.0)
+        duration = len(samples) / 16_000
+        if max_tokens is None:
+            max_tokens = max(256, int(duration * 50))
+        lang = self._resolve_language(language)
+        if duration > chunk_duration:
+            return self._transcribe_chunked(samples, duration, lang, temperature, top_p, top_k, repetition_penalty,
+                                            repetition_context_size, chunk_duration)
+        text = self._run_jobs([(0, samples, max_tokens)], lang, temperature, top_p, top_k, repetition_penalty,
+                              repetition_context_size)[0]
+        return TranscriptionResult(text=text, language=lang, duration=duration)
+
+    def _transcribe_chunked(self, samples, duration, lang, temperature, top_p, top_k, repetition_penalty,
+                            repetition_context_size, chunk_duration) -> TranscriptionResult:
+        """Segments split at low-energy points (model.py:382-447).  They are independent, so they are
+        decoded as one batch instead of sequentially."""
+        chunk_samples = int(chunk_duration * 16_000)
+        points = _find_split_points(samples, chunk_samples, int(5.0 * 16_000))
+        jobs, prev = [], 0
+        for sp in points + [len(samples)]:
+            seg = samples[prev:sp]
+            prev = sp
+            if len(seg):
+                jobs.append((0, seg, max(256, int(len(seg) / 16_000 * 50))))
+        texts = self._run_jobs(jobs, lang, temperature, top_p, top_k, repetition_penalty, repetition_context_size)
+        return TranscriptionResult(text=" ".join(t for t in texts if t), language=lang, duration=duration)
+
+    def _run_jobs(self, jobs, lang, temperature, top_p, top_k, repetition_penalty, repetition_context_size) -> list[str]:
+        """mel -> encoder -> prompt -> generate -> detokenise for a list of (idx, samples, max_tokens)."""
+        texts: list[str] = [""] * len(jobs)
+        order = sorted(range(len(jobs)), key=lambda j: -len(jobs[j][1]))      # similar lengths share a batch
+        for s in range(0, len(order), self.MAX_BATCH):
+            sel = order[s: s + self.MAX_BATCH]
+            toks = self.generate_tokens([jobs[j][1] for j in sel], [jobs[j][2] for j in sel], lang, temperature, top_p,
+                                        top_k, repetition_penalty, repetition_context_size)
+            for j, t in zip(sel, toks):
+                texts[j] = self._decode_output(t)
+        return texts
+
+    def generate_tokens(self, batch: Sequence[np.ndarray], max_tokens: Sequence[int], lang: str, temperature=0.0,
+                        top_p=1.0, top_k=0, repetition_penalty=1.2, repetition_context_size=100) -> list[list[int]]:
+        """The device part of the hot path for <= MAX_BATCH utterances (steps 5-8 of model.py:330-352)."""
+        if self._encoder is None or self._decoder is None:
+            raise TypeError("'NoneType' object is not callable")             # use after close(), as the reference
+        dev = self._decoder.device
+        fe = get_frontend(dev)
+        audio, lens_dev, lens = pack_audio(batch, dev)
+        mel, n_frames = fe(audio, lens_dev, lens)
+        feats, tok_counts = self._encoder.forward_batch(mel, n_frames)
+        lang_ids = self._tokenizer.encode(f" {lang}")
+        from .tokenizer import build_prompt
+        prompts = [build_prompt(n, lang_ids) for n in tok_counts]
+        return generate_batch(self._decoder, feats, tok_counts, prompts, list(max_tokens), temperature, top_p, top_k,
+                              repetition_penalty, repetition_context_size, seed=_next_seed() if temperature else 0,
+                              use_graph=self.use_graph)
+
+    def _resolve_language(self, language: Optional[str]) -> str:
+        if language is None or language.lower() in ("auto", ""):
+            return "English"
+        return LANGUAGE_MAP.get(language.lower(), language)
+
+    def _decode_output(self, tokens: list[int]) -> str:
+        tokens = list(tokens)
+        while tokens and tokens[-1] in EOS_TOKEN_IDS:
+            tokens.pop()
+        return self._tokenizer.decode(tokens, skip_special_tokens=True).strip()

@@ -1,0 +1,432 @@
+"""Per-kernel parity on the GPU: every C-ABI entry point against the oracle / a float32 torch
+restatement of the same op, on seeded inputs, including the ragged / edge shapes."""
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from signals import signal
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def bfr(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def rnd(shape, dev, seed, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+# ----------------------------------------------------------------------------- mel
+def test_mel_matches_reference_golden_and_oracle(dev):
+    import oracle
+    import qwen3_asr_mlx_amd as q
+    full = np.load(GOLD / "mel_full.npz")
+    for key in full.files:
+        if "_n" in key:
+            x = signal("noise", int(key.split("_n")[1]))
+        else:
+            kind, s = key.split("_")
+            x = signal(kind, int(float(s[:-1]) * 16000))
+        got = q.log_mel_spectrogram(x).cpu().numpy()
+        assert got.shape == full[key].shape
+        # tolerance: 2e-6 abs on the normalised log-mel (fp64-accumulated DFT vs pocketfft float32)
+        np.testing.assert_allclose(got, full[key], atol=2e-6, rtol=0, err_msg=key)
+    dg = json.loads((GOLD / "mel_digest.json").read_text())
+    for kind in ("tone", "noise", "speechlike", "silence"):
+        x = signal(kind, 480000)
+        got = q.log_mel_spectrogram(x).cpu().numpy()
+        assert list(got.shape) == dg[f"{kind}_30s"]["shape"]
+        ref = np.array(dg[f"{kind}_30s"]["every97"], dtype=np.float32)
+        np.testing.assert_allclose(got.reshape(-1)[::97][:4096], ref, atol=2e-6, rtol=0)
+        np.testing.assert_allclose(got, oracle.log_mel_spectrogram(x), atol=2e-6, rtol=0)
+
+
+def test_mel_batch_is_ragged_safe_and_batch_invariant(dev):
+    import oracle
+    from qwen3_asr_mlx_amd import audio
+    xs = [signal("noise", 80000), signal("tone", 16000), signal("noise", 1234), signal("silence", 8000),
+          signal("speechlike", 48077)]
+    fe = audio.get_frontend(dev)
+    a, ld, lens = audio.pack_audio(xs, dev)
+    mel, nfr = fe(a, ld, lens)
+    assert nfr == [len(x) // 160 for x in xs]
+    for i, x in enumerate(xs):
+        got = mel[i, :, : nfr[i]].cpu().numpy()
+        np.testing.assert_allclose(got, oracle.log_mel_spectrogram(x), atol=2e-6, rtol=0)
+        assert float(mel[i, :, nfr[i]:].abs().max().item() if nfr[i] < mel.shape[2] else 0.0) == 0.0
+        single = audio.log_mel_spectrogram(x)
+        assert torch.equal(single, mel[i, :, : nfr[i]])          # bitwise: independent of batch mates
+    assert np.all(mel[3, :, : nfr[3]].cpu().numpy() == -1.5)      # reference test_audio.py:80-89
+
+
+def test_mel_rejects_too_short(dev):
+    import qwen3_asr_mlx_amd as q
+    with pytest.raises(ValueError):
+        q.log_mel_spectrogram(np.zeros(100, dtype=np.float32))
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("M,D", [(1, 256), (7, 1024), (390, 1024), (33, 2048)])
+def test_layernorm(dev, M, D):
+    from qwen3_asr_mlx_amd import ops
+    x = rnd((M, D), dev, 1, 2.0, torch.float32) + 0.5
+    w = rnd((D,), dev, 2, 1.0, torch.float32)
+    b = rnd((D,), dev, 3, 1.0, torch.float32)
+    y = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+    ops.layernorm(x, w, b, y, M, D, 1e-5)
+    ref = F.layer_norm(x.cpu(), (D,), w.cpu(), b.cpu(), 1e-5)
+    # bf16 output: half an ulp of the bf16 result plus float32 reduction-order noise
+    torch.testing.assert_close(y.float().cpu(), bfr(ref), atol=2e-2, rtol=8e-3)
+    assert (y.float().cpu() - ref).abs().max() < 4e-2
+
+
+@pytest.mark.parametrize("M,D", [(1, 512), (5, 2048), (408, 2048), (9, 4096)])
+def test_rmsnorm_and_row_gather(dev, M, D):
+    import oracle.decoder as od
+    from qwen3_asr_mlx_amd import ops
+    x = rnd((M, D), dev, 4, 1.5)
+    w = rnd((D,), dev, 5, 1.0)
+    y = torch.empty_like(x)
+    ops.rmsnorm(x, w, y, M, D, 1e-6)
+    ref = od.rms_norm(x.float().cpu(), w.float().cpu(), 1e-6)
+    torch.testing.assert_close(y.float().cpu(), ref, atol=0, rtol=8e-3)   # <= 1 bf16 ulp
+    idx = torch.tensor([M - 1, 0], dtype=torch.int32, device=dev)
+    y2 = torch.empty((2, D), dtype=torch.bfloat16, device=dev)
+    ops.rmsnorm(x, w, y2, 2, D, 1e-6, row_idx=idx)
+    assert torch.equal(y2[0], y[M - 1]) and torch.equal(y2[1], y[0])
+
+
+# ----------------------------------------------------------------------------- GEMM
+def _gemm_ref(A, W, bias=None, act=0, res=None, res_kind=0, res_mod=0):
+    c = A.float().cpu() @ W.float().cpu().T
+    if bias is not None:
+        c = c + bias.cpu()
+    if act == 1:
+        c = F.gelu(c)
+    if res_kind == 1:
+        r = res.cpu()
+        c = c + (r[torch.arange(c.shape[0]) % res_mod] if res_mod else r)
+    elif res_kind == 2:
+        c = bfr(c) + res.float().cpu()
+    return c
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 256, 192), (257, 480, 4320), (1000, 384, 1024), (64, 1024, 7680)])
+def test_gemm_plain_and_edges(dev, M, N, K):
+    from qwen3_asr_mlx_amd import ops
+    A = rnd((M, K), dev, 10, 1.0)
+    W = rnd((N, K), dev, 11, 1.0 / math.sqrt(K))
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    ops.gemm(A, W, M, N, K, out, out_fp32=True)
+    ref = _gemm_ref(A, W)
+    torch.testing.assert_close(out.cpu(), ref, atol=2e-3, rtol=1e-3)      # float32 accumulation order only
+    outb = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, M, N, K, outb)
+    torch.testing.assert_close(outb.float().cpu(), bfr(ref), atol=2e-2, rtol=8e-3)
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I against an asymmetric W catches a transposed C write or operand swap exactly."""
+    from qwen3_asr_mlx_amd import ops
+    K = 256
+    A = torch.eye(K, dtype=torch.bfloat16, device=dev)
+    W = (torch.arange(384 * K, dtype=torch.float32).reshape(384, K) % 251 - 125).to(torch.bfloat16).to(dev)
+    out = torch.empty((K, 384), dtype=torch.float32, device=dev)
+    ops.gemm(A, W, K, 384, K, out, out_fp32=True)
+    assert torch.equal(out.cpu(), W.float().cpu().T)
+
+
+def test_gemm_epilogues(dev):
+    from qwen3_asr_mlx_amd import ops
+    M, N, K = 300, 512, 256
+    A = rnd((M, K), dev, 20)
+    W = rnd((N, K), dev, 21, 1.0 / math.sqrt(K))
+    bias = rnd((N,), dev, 22, 0.5, torch.float32)
+    # bias + GELU -> bf16
+    o = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, W, M, N, K, o, bias=bias, act=1)
+    torch.testing.assert_close(o.float().cpu(), bfr(_gemm_ref(A, W, bias, 1)), atol=2e-2, rtol=8e-3)
+    # bias + fp32 residual, in place
+    h = rnd((M, N), dev, 23, 1.0, torch.float32)
+    h0 = h.clone()
+    ops.gemm(A, W, M, N, K, h, bias=bias, res=h, res_kind=1, ldres=N, out_fp32=True)
+    torch.testing.assert_close(h.cpu(), _gemm_ref(A, W, bias, 0, h0, 1), atol=2e-3, rtol=1e-3)
+    # bf16 residual with MLX rounding
+    hb = rnd((M, N), dev, 24)
+    hb0 = hb.clone()
+    ops.gemm(A, W, M, N, K, hb, res=hb, res_kind=2, ldres=N)
+    torch.testing.assert_close(hb.float().cpu(), bfr(_gemm_ref(A, W, None, 0, hb0, 2)), atol=2e-2, rtol=8e-3)
+    # residual indexed modulo 13 + row map with dropped rows (conv_out + PE + pad strip)
+    pe = rnd((13, N), dev, 25, 1.0, torch.float32)
+    rm = torch.tensor([(i * 7) % M if i % 5 else -1 for i in range(M)], dtype=torch.int32)
+    keep = rm >= 0
+    rm[keep] = torch.arange(int(keep.sum()), dtype=torch.int32)
+    out = torch.zeros((int(keep.sum()), N), dtype=torch.float32, device=dev)
+    ops.gemm(A, W, M, N, K, out, res=pe, res_kind=1, ldres=N, res_mod=13, out_fp32=True, row_map=rm.to(dev))
+    torch.testing.assert_close(out.cpu(), _gemm_ref(A, W, None, 0, pe, 1, 13)[keep], atol=2e-3, rtol=1e-3)
+
+
+def test_gemm_swiglu(dev):
+    from qwen3_asr_mlx_amd import ops
+    M, I, K = 200, 256, 512
+    A = rnd((M, K), dev, 30)
+    gate = rnd((I, K), dev, 31, 2.0 / math.sqrt(K))
+    up = rnd((I, K), dev, 32, 2.0 / math.sqrt(K))
+    gu = torch.stack([gate.reshape(I // 16, 16, K), up.reshape(I // 16, 16, K)], 1).reshape(2 * I, K).contiguous()
+    o = torch.empty((M, I), dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, gu, M, 2 * I, K, o, act=2)
+    g, u = bfr(A.float().cpu() @ gate.float().cpu().T), bfr(A.float().cpu() @ up.float().cpu().T)
+    ref = bfr(g * torch.sigmoid(g) * u)
+    torch.testing.assert_close(o.float().cpu(), ref, atol=2e-2, rtol=1.6e-2)
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    from qwen3_asr_mlx_amd import ops
+    A = rnd((4, 60), dev, 1)
+    W = rnd((8, 60), dev, 2)
+    with pytest.raises(ValueError):
+        ops.gemm(A, W, 4, 8, 60, torch.empty((4, 8), dtype=torch.bfloat16, device=dev))   # K % 8 != 0
+
+
+# ----------------------------------------------------------------------------- conv stem
+def test_conv1_gelu(dev):
+    from qwen3_asr_mlx_amd import ops
+    C1, B, Fmax = 32, 2, 230
+    mel = rnd((B, 128, Fmax), dev, 40, 1.0, torch.float32)
+    w = rnd((C1, 3, 3, 1), dev, 41, 0.3)                       # MLX (O, kH=freq, kW=time, I)
+    b = rnd((C1,), dev, 42, 0.2, torch.float32)
+    chunks = [(0, 0), (0, 100), (0, 200), (1, 0), (1, 100)]    # (utterance, first frame); 200.. is ragged (30 frames)
+    cb = torch.tensor([c[0] for c in chunks], dtype=torch.int32, device=dev)
+    cf = torch.tensor([c[1] for c in chunks], dtype=torch.int32, device=dev)
+    out = torch.empty((len(chunks), 50, 64, C1), dtype=torch.bfloat16, device=dev)
+    w9 = w.float()[..., 0].permute(0, 2, 1).contiguous()
+    ops.call("q3asr_conv1_gelu", ops.ptr(mel), Fmax, ops.ptr(cb), ops.ptr(cf), len(chunks), ops.ptr(w9), ops.ptr(b),
+             ops.ptr(out), C1, ops.sp())
+    melc = mel.cpu()
+    for i, (ub, f0) in enumerate(chunks):
+        x = torch.zeros(128, 100)
+        n = max(0, min(100, Fmax - f0))
+        x[:, :n] = melc[ub, :, f0: f0 + n]
+        ref = F.gelu(F.conv2d(x[None, None], w.float().cpu().permute(0, 3, 1, 2), b.cpu(), stride=2, padding=1))[0]
+        got = out[i].float().cpu().permute(2, 1, 0)            # [t][f][c] -> [c][f][t]
+        torch.testing.assert_close(got, bfr(ref), atol=1e-2, rtol=8e-3)
+
+
+@pytest.mark.parametrize("imgs,H,W_,C", [(3, 50, 64, 32), (2, 25, 32, 32), (5, 13, 16, 480)])
+def test_conv3x3s2_implicit_gemm(dev, imgs, H, W_, C):
+    from qwen3_asr_mlx_amd import ops
+    x = rnd((imgs, H, W_, C), dev, 50)
+    w = rnd((C, 3, 3, C), dev, 51, 1.0 / math.sqrt(9 * C))
+    b = rnd((C,), dev, 52, 0.3, torch.float32)
+    Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
+    out = torch.empty((imgs, Ho, Wo, C), dtype=torch.bfloat16, device=dev)
+    ops.conv3x3s2(x, imgs, H, W_, C, w.reshape(C, 9 * C), C, b, 1, out)
+    ref = F.gelu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), b.cpu(), stride=2, padding=1))
+    torch.testing.assert_close(out.float().cpu(), bfr(ref.permute(0, 2, 3, 1)), atol=2e-2, rtol=8e-3)
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale, causal):
+    """q (Tq,D) k,v (Tk,D) float32; softmax fp32, P rounded to bf16 for PV, sum unrounded."""
+    s = (q @ k.T) * scale
+    if causal:
+        s = s.masked_fill(torch.arange(k.shape[0])[None] > torch.arange(q.shape[0])[:, None], float("-inf"))
+    m = s.max(-1, keepdim=True).values
+    p = torch.exp(s - m)
+    return (bfr(p) @ v) / p.sum(-1, keepdim=True)
+
+
+def test_attn_fwd_encoder_windows(dev):
+    from qwen3_asr_mlx_amd import ops
+    nh, hd = 4, 64
+    d = nh * hd
+    lens = [104, 104, 27, 1, 65, 104]
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).tolist()
+    N = sum(lens)
+    qkv = rnd((N, 3 * d), dev, 60, 1.0)
+    out = torch.zeros((N, d), dtype=torch.bfloat16, device=dev)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    kv_off = torch.tensor([s * 3 * d for s in starts], dtype=torch.int64, device=dev)
+    ops.attn_fwd(ops.ptr(qkv), 3 * d, ops.off_ptr(qkv, d), ops.off_ptr(qkv, 2 * d), kv_off, hd, 3 * d, out, d,
+                 i32(starts), i32(lens), len(lens), max(lens), nh, nh, hd, False, hd ** -0.5)
+    c = qkv.float().cpu()
+    for s, n in zip(starts, lens):
+        for h in range(nh):
+            q_, k_, v_ = (c[s: s + n, o + h * hd: o + (h + 1) * hd] for o in (0, d, 2 * d))
+            ref = _attn_ref(q_, k_, v_, hd ** -0.5, False)
+            torch.testing.assert_close(out[s: s + n, h * hd: (h + 1) * hd].float().cpu(), bfr(ref), atol=2e-2, rtol=1.6e-2)
+
+
+@pytest.mark.parametrize("lens", [[1], [64], [65, 130, 7], [408, 83]])
+def test_attn_fwd_decoder_causal_gqa(dev, lens):
+    from qwen3_asr_mlx_amd import ops
+    nh, nkv, hd, Lmax = 4, 2, 128, 448
+    B = len(lens)
+    M = sum(lens)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).tolist()
+    q = rnd((M, nh * hd), dev, 70)
+    kc = rnd((B, nkv, Lmax, hd), dev, 71)
+    vc = rnd((B, nkv, Lmax, hd), dev, 72)
+    out = torch.zeros((M, nh * hd), dtype=torch.bfloat16, device=dev)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    kv_off = torch.tensor([b * nkv * Lmax * hd for b in range(B)], dtype=torch.int64, device=dev)
+    ops.attn_fwd(ops.ptr(q), nh * hd, ops.ptr(kc), ops.ptr(vc), kv_off, Lmax * hd, hd, out, nh * hd, i32(starts), i32(lens),
+                 B, max(lens), nh, nkv, hd, True, hd ** -0.5)
+    qc, kcc, vcc = q.float().cpu(), kc.float().cpu(), vc.float().cpu()
+    for b, (s, n) in enumerate(zip(starts, lens)):
+        for h in range(nh):
+            ref = _attn_ref(qc[s: s + n, h * hd: (h + 1) * hd], kcc[b, h // 2, :n], vcc[b, h // 2, :n], hd ** -0.5, True)
+            torch.testing.assert_close(out[s: s + n, h * hd: (h + 1) * hd].float().cpu(), bfr(ref), atol=2e-2, rtol=1.6e-2)
+
+
+def test_attn_online_softmax_rescale_branch(dev):
+    """Force the running max to jump at a later key tile (a spike in tile 3) -- the rescale path."""
+    from qwen3_asr_mlx_amd import ops
+    nh, nkv, hd, T = 2, 1, 128, 256
+    q = rnd((T, nh * hd), dev, 73, 0.3)
+    kc = rnd((1, nkv, T, hd), dev, 74, 0.3)
+    vc = rnd((1, nkv, T, hd), dev, 75)
+    kc[0, 0, 200] = q[255, :hd] * 6.0                           # key 200 matches the last query strongly
+    out = torch.zeros((T, nh * hd), dtype=torch.bfloat16, device=dev)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    ops.attn_fwd(ops.ptr(q), nh * hd, ops.ptr(kc), ops.ptr(vc), torch.zeros(1, dtype=torch.int64, device=dev), T * hd, hd,
+                 out, nh * hd, i32([0]), i32([T]), 1, T, nh, nkv, hd, True, hd ** -0.5)
+    for h in range(nh):
+        ref = _attn_ref(q.float().cpu()[:, h * hd: (h + 1) * hd], kc.float().cpu()[0, 0], vc.float().cpu()[0, 0], hd ** -0.5, True)
+        torch.testing.assert_close(out[:, h * hd: (h + 1) * hd].float().cpu(), bfr(ref), atol=2e-2, rtol=1.6e-2)
+
+
+@pytest.mark.parametrize("B,poss", [(1, [0]), (3, [5, 63, 200]), (2, [408, 535])])
+def test_attn_decode(dev, B, poss):
+    from qwen3_asr_mlx_amd import ops
+    nh, nkv, hd, Lmax = 4, 2, 128, 576
+    q = rnd((B, nh * hd), dev, 80)
+    kc = rnd((B, nkv, Lmax, hd), dev, 81)
+    vc = rnd((B, nkv, Lmax, hd), dev, 82)
+    out = torch.zeros((B, nh * hd), dtype=torch.bfloat16, device=dev)
+    pos = torch.tensor(poss, dtype=torch.int32, device=dev)
+    ops.call("q3asr_attn_decode", ops.ptr(q), ops.ptr(kc), ops.ptr(vc), ops.ptr(pos), ops.ptr(out), B, nh, nkv, hd, Lmax,
+             hd ** -0.5, ops.sp())
+    for b in range(B):
+        L = poss[b] + 1
+        for h in range(nh):
+            ref = _attn_ref(q.float().cpu()[b: b + 1, h * hd: (h + 1) * hd], kc.float().cpu()[b, h // 2, :L],
+                            vc.float().cpu()[b, h // 2, :L], hd ** -0.5, False)
+            torch.testing.assert_close(out[b: b + 1, h * hd: (h + 1) * hd].float().cpu(), bfr(ref), atol=2e-2, rtol=1.6e-2)
+
+
+# ----------------------------------------------------------------------------- rope / kv / embed
+def test_qk_norm_rope_kv_bf16_and_slab(dev):
+    import oracle.decoder as od
+    from qwen3_asr_mlx_amd import ops
+    nh, nkv, hd, Lmax, B = 4, 2, 128, 64, 3
+    rows_b = [0, 0, 0, 1, 2, 2]
+    rows_p = [0, 1, 2, 40, 7, 63]
+    M = len(rows_b)
+    qkvd = (nh + 2 * nkv) * hd
+    qkv = rnd((M, qkvd), dev, 90, 2.0)
+    qn, kn = rnd((hd,), dev, 91, 1.0) + 1, rnd((hd,), dev, 92, 1.0) + 1
+    theta = 1e6
+    inv = (theta ** (-torch.arange(64, dtype=torch.float32) / 64)).to(dev)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+
+    def run(src, is_slab, n_slabs, stride):
+        qo = torch.zeros((M, nh * hd), dtype=torch.bfloat16, device=dev)
+        kc = torch.zeros((B, nkv, Lmax, hd), dtype=torch.bfloat16, device=dev)
+        vc = torch.zeros_like(kc)
+        ops.call("q3asr_qk_norm_rope_kv", ops.ptr(src), is_slab, qkvd, n_slabs, stride, ops.ptr(i32(rows_b)), ops.ptr(i32(rows_p)),
+                 ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6, ops.ptr(qo), ops.ptr(kc), ops.ptr(vc), M, nh, nkv, hd, Lmax, ops.sp())
+        return qo, kc, vc
+
+    qo, kc, vc = run(qkv, 0, 0, 0)
+    c = qkv.float().cpu()
+    for m in range(M):
+        pos = torch.tensor([rows_p[m]])
+        qr = od.rope(od.rms_norm(c[m, : nh * hd].reshape(nh, 1, hd), qn.float().cpu(), 1e-6), pos, theta)
+        kr = od.rope(od.rms_norm(c[m, nh * hd: (nh + nkv) * hd].reshape(nkv, 1, hd), kn.float().cpu(), 1e-6), pos, theta)
+        # <= 1 bf16 ulp (device sincos vs torch) on O(1) values
+        torch.testing.assert_close(qo[m].float().cpu().reshape(nh, 1, hd), qr, atol=4e-2, rtol=1.6e-2)
+        torch.testing.assert_close(kc[rows_b[m], :, rows_p[m]].float().cpu()[:, None], kr, atol=4e-2, rtol=1.6e-2)
+        assert torch.equal(vc[rows_b[m], :, rows_p[m]].cpu().reshape(-1), qkv[m, (nh + nkv) * hd:].cpu())
+    # norm-preservation (reference test_decoder.py:107-126): rotation keeps the per-head norm
+    n_in = od.rms_norm(c[:, : nh * hd].reshape(M, nh, hd), qn.float().cpu(), 1e-6).norm(dim=-1)
+    torch.testing.assert_close(qo.float().cpu().reshape(M, nh, hd).norm(dim=-1), n_in, atol=0, rtol=2e-2)
+    # slab input: three fp32 partials whose sum rounds to the same bf16 values
+    parts = torch.stack([c * 0.5, c * 0.25, c * 0.25]).to(dev)
+    qo2, kc2, vc2 = run(parts, 1, 3, M * qkvd)
+    assert torch.equal(qo2, qo) and torch.equal(kc2, kc) and torch.equal(vc2, vc)
+
+
+def test_embed_merge(dev):
+    from qwen3_asr_mlx_amd import ops
+    V, H = 300, 512
+    E = rnd((V, H), dev, 100)
+    enc = rnd((5, H), dev, 101, 1.0, torch.float32)
+    ids = torch.tensor([3, 7, 299, 299, 0, 299, 299, 299, 8], dtype=torch.int32, device=dev)
+    src = torch.tensor([-1, -1, 0, 1, -1, 2, 3, 4, -1], dtype=torch.int32, device=dev)
+    out = torch.empty((9, H), dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_embed_merge", ops.ptr(ids), ops.ptr(src), ops.ptr(E), ops.ptr(enc), ops.ptr(out), 9, H, ops.sp())
+    for m in range(9):
+        want = enc[src[m]].to(torch.bfloat16) if src[m] >= 0 else E[ids[m]]
+        assert torch.equal(out[m], want)
+
+
+# ----------------------------------------------------------------------------- decode-step kernels
+@pytest.mark.parametrize("M,N,K,S", [(1, 256, 512, 2), (7, 4096, 2048, 8), (32, 2048, 6144, 24), (33, 1024, 512, 1),
+                                     (64, 2048, 2048, 4), (16, 200, 256, 1)])
+def test_skinny_gemm_slabs(dev, M, N, K, S):
+    from qwen3_asr_mlx_amd import ops
+    X = rnd((M, K), dev, 110)
+    W = rnd((N, K), dev, 111, 1.0 / math.sqrt(K))
+    slab = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+    ops.call("q3asr_skinny_gemm", ops.ptr(X), K, M, ops.ptr(W), K, N, K, S, ops.ptr(slab), None, N, ops.sp())
+    ref = X.float().cpu() @ W.float().cpu().T
+    torch.testing.assert_close(slab.sum(0).cpu(), ref, atol=2e-3, rtol=1e-3)
+    if S == 1:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        ops.skinny_gemm(X, M, W, N, K, 1, None, out)
+        torch.testing.assert_close(out.float().cpu(), bfr(ref), atol=2e-2, rtol=8e-3)
+
+
+def test_skinny_gemm_identity_layout(dev):
+    from qwen3_asr_mlx_amd import ops
+    K = 512
+    X = torch.eye(K, dtype=torch.bfloat16, device=dev)[:48].contiguous()          # rows e_0..e_47
+    W = (torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 241 - 120).to(torch.bfloat16).to(dev)
+    out = torch.empty((48, 192), dtype=torch.bfloat16, device=dev)
+    ops.skinny_gemm(X, 48, W, 192, K, 1, None, out)
+    assert torch.equal(out.float().cpu(), W.float().cpu()[:, :48].T)
+
+
+def test_slab_consumers_and_embed_rmsnorm(dev):
+    import oracle.decoder as od
+    from qwen3_asr_mlx_amd import ops
+    M, N, S, I = 5, 2048, 3, 1024
+    slab = rnd((S, M, N), dev, 120, 0.5, torch.float32)
+    h = rnd((M, N), dev, 121)
+    w = rnd((N,), dev, 122) + 1
+    ho, xo = torch.empty_like(h), torch.empty_like(h)
+    ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(slab), S, M * N, ops.ptr(h), ops.ptr(ho), ops.ptr(w), ops.ptr(xo), M, N, 1e-6, ops.sp())
+    tot = (slab[0] + slab[1] + slab[2]).cpu()
+    href = bfr(bfr(tot) + h.float().cpu())
+    assert torch.equal(ho.float().cpu(), href)
+    torch.testing.assert_close(xo.float().cpu(), od.rms_norm(href, w.float().cpu(), 1e-6), atol=0, rtol=8e-3)
+    sl2 = rnd((S, M, 2 * I), dev, 123, 0.7, torch.float32)
+    act = torch.empty((M, I), dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_slab_swiglu", ops.ptr(sl2), S, M * 2 * I, ops.ptr(act), M, I, ops.sp())
+    t2 = (sl2[0] + sl2[1] + sl2[2]).cpu().reshape(M, I // 16, 2, 16)
+    g, u = bfr(t2[:, :, 0].reshape(M, I)), bfr(t2[:, :, 1].reshape(M, I))
+    torch.testing.assert_close(act.float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=1e-3, rtol=8e-3)
+    E = rnd((50, N), dev, 124)
+    tok = torch.tensor([3, 49, 0, 3, 7], dtype=torch.int32, device=dev)
+    ops.call("q3asr_embed_rmsnorm", ops.ptr(tok), ops.ptr(E), ops.ptr(ho), ops.ptr(w), ops.ptr(xo), M, N, 1e-6, ops.sp())
+    assert torch.equal(ho, E[tok.long()])
+    torch.testing.assert_close(xo.float().cpu(), od.rms_norm(E[tok.long()].float().cpu(), w.float().cpu(), 1e-6), atol=0, rtol=8e-3)
