@@ -1,0 +1,163 @@
+"""Product-package host logic and the C-ABI symbol table on CPU (no compute calls without a GPU)."""
+import ctypes
+import json
+import re
+import struct
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from signals import signal
+
+GOLD = Path(__file__).parent / "golden"
+ROOT = Path(__file__).parent.parent
+
+
+def test_package_exports_match_reference_surface():
+    import qwen3_asr_mlx_amd as q
+    names = ["__version__", "load_audio", "log_mel_spectrogram", "AudioEncoderConfig", "TextDecoderConfig", "ModelConfig",
+             "AudioEncoder", "load_encoder_weights", "KVCache", "TextDecoder", "load_decoder_weights", "generate",
+             "prepare_inputs", "sample", "Tokenizer", "build_prompt", "parse_output", "Qwen3ASR", "TranscriptionResult",
+             "LANGUAGE_MAP"]
+    assert q.__all__ == names and all(hasattr(q, n) for n in names)
+    import inspect
+    sig = inspect.signature(q.Qwen3ASR.transcribe)
+    assert [(p.name, p.default) for p in list(sig.parameters.values())[2:]] == [
+        ("language", None), ("temperature", 0.0), ("top_p", 1.0), ("top_k", 0), ("repetition_penalty", 1.2),
+        ("max_tokens", None), ("repetition_context_size", 100), ("chunk_duration", 1200.0)]
+    sig = inspect.signature(q.generate)
+    assert sig.parameters["max_tokens"].default == 8192 and sig.parameters["repetition_penalty"].default == 1.0
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import qwen3_asr_mlx_amd as q
+    h = q._lib.load()
+    header = (ROOT / "include" / "q3asr.h").read_text()
+    declared = set(re.findall(r"\b(q3asr_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(q._lib.EXPORTS)
+    raw = ctypes.CDLL(str(q._lib.LIB_PATH))
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert h.q3asr_arch() == b"gfx950" and h.q3asr_version() == 100
+    # argument validation is host-side and must not touch a device
+    assert h.q3asr_gemm_bf16(None, 0, None, 0, 1, 1, 1, None, 0, None, 0, 0, 0, None, 0, 0, None, None) == -1
+    assert b"null pointer" in h.q3asr_last_error()
+    with pytest.raises(ValueError):
+        q._lib.call("q3asr_skinny_gemm", None, 0, 1, None, 0, 64, 256, 1, None, None, 64, None)
+
+
+def test_filterbank_and_prompt_and_splitter_match_fixtures():
+    from qwen3_asr_mlx_amd import audio, model, tokenizer
+    assert np.array_equal(audio._get_mel_filterbank(), np.load(GOLD / "mel_filterbank.npy"))
+    assert audio._get_mel_filterbank() is audio._get_mel_filterbank()
+    pr = json.loads((GOLD / "prompts.json").read_text())
+    for n in (0, 13, 65, 390):
+        assert tokenizer.build_prompt(n) == pr[f"n{n}_none"]
+        assert tokenizer.build_prompt(n, [6364]) == pr[f"n{n}_lang"]
+    for s, want in pr["parse_output"]:
+        assert tokenizer.parse_output(s) == want
+    c = pr["constants"]
+    assert (tokenizer.AUDIO_PAD_TOKEN_ID, tokenizer.ASR_TEXT_TOKEN_ID, sorted(tokenizer.EOS_TOKEN_IDS)) == (
+        c["AUDIO_PAD_TOKEN_ID"], c["ASR_TEXT_TOKEN_ID"], c["EOS_TOKEN_IDS"])
+    sp = json.loads((GOLD / "split_points.json").read_text())
+    sr = 16000
+    f = model._find_split_points
+    assert f(np.random.default_rng(0).random(int(sr * 25)).astype(np.float32), sr * 10, 5 * sr) == sp["rng0_2.5chunks"]
+    assert f(np.random.default_rng(2).random(sr * 25).astype(np.float32), sr * 5, 2 * sr) == sp["rng2_5x5s"]
+    long = (np.random.default_rng(3).standard_normal(sr * 1200) * 0.1).astype(np.float32)
+    got = f(long, 30 * sr, 5 * sr)
+    assert got == sp["rng3_20min_30s"] and len(got) == 39 and got[:3] == [485280, 928800, 1394400]
+    assert f(np.ones(100, np.float32), 50, 10) == []
+
+
+def test_config_parsing():
+    """reference tests/test_config.py: nested audio block, flat text keys, defaults, local dir."""
+    from qwen3_asr_mlx_amd import ModelConfig, AudioEncoderConfig, TextDecoderConfig
+    from qwen3_asr_mlx_amd import synth
+    d = {"audio_encoder_config": {"d_model": 512, "num_hidden_layers": 6, "n_window": 50, "output_dim": 1024},
+         "hidden_size": 1024, "num_hidden_layers": 12, "rope_theta": 5e5, "audio_token_id": 9}
+    c = ModelConfig.from_dict(d)
+    assert (c.audio_encoder.d_model, c.audio_encoder.encoder_layers, c.audio_encoder.output_dim) == (512, 6, 1024)
+    assert (c.text_decoder.hidden_size, c.text_decoder.num_hidden_layers, c.text_decoder.rope_theta) == (1024, 12, 5e5)
+    assert c.audio_token_id == 9 and c.audio_start_token_id == 151669
+    assert c.audio_encoder.encoder_ffn_dim == 4096 and c.text_decoder.mrope_section == [24, 20, 20]
+    dflt = ModelConfig()
+    assert dflt.audio_encoder == AudioEncoderConfig() and dflt.text_decoder == TextDecoderConfig()
+    assert (dflt.text_decoder.vocab_size, dflt.text_decoder.head_dim, dflt.audio_encoder.downsample_hidden_size) == (151936, 128, 480)
+    assert ModelConfig.from_dict(synth.config_dict(synth.small_config())) == synth.small_config()
+
+
+def test_config_from_local_dir(tmp_path):
+    from qwen3_asr_mlx_amd import ModelConfig
+    (tmp_path / "config.json").write_text(json.dumps({"hidden_size": 256, "audio_encoder_config": {"d_model": 128}}))
+    c = ModelConfig.from_pretrained(tmp_path)
+    assert c.text_decoder.hidden_size == 256 and c.audio_encoder.d_model == 128
+
+
+def test_language_map_and_result_dataclass():
+    from qwen3_asr_mlx_amd import LANGUAGE_MAP, TranscriptionResult
+    assert LANGUAGE_MAP["en"] == "English" and LANGUAGE_MAP["zh"] == "Chinese" and LANGUAGE_MAP["is"] == "Icelandic"
+    assert len(LANGUAGE_MAP) == 67
+    r = TranscriptionResult(text="a", language="English", duration=1.5)
+    assert (r.text, r.language, r.duration) == ("a", "English", 1.5)
+    assert max(256, int(30.0 * 50)) == 1500 and max(256, int(1.0 * 50)) == 256       # model.py:309-310
+
+
+def test_wav_reader_and_resampler(tmp_path):
+    from qwen3_asr_mlx_amd import load_audio
+    sr = 8000
+    x = (np.sin(np.arange(800) * 0.1) * 0.5).astype(np.float32)
+    pcm = (x * 32767).astype("<i2")
+    stereo = np.stack([pcm, pcm], axis=1).reshape(-1)
+
+    def wav(path, tag, bits, ch, data):
+        fmt = struct.pack("<HHIIHH", tag, ch, sr, sr * ch * bits // 8, ch * bits // 8, bits)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 4) + b"abcd" \
+            + b"data" + struct.pack("<I", len(data)) + data
+        path.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+    wav(tmp_path / "a.wav", 1, 16, 2, stereo.tobytes())
+    y = load_audio(tmp_path / "a.wav")
+    assert y.dtype == np.float32 and len(y) == int(800 * 16000 / 8000)
+    ref = pcm.astype(np.float32) / 32768.0
+    want = np.interp(np.linspace(0.0, 799, 1600), np.arange(800), ref).astype(np.float32)
+    assert np.allclose(y, want, atol=1e-7)
+    wav(tmp_path / "f.wav", 3, 32, 1, x.tobytes())
+    assert np.array_equal(load_audio(tmp_path / "f.wav", target_sr=sr), x)
+
+
+def test_encoder_plan_and_masks_cpu():
+    """Host-side batch plan: chunk table, pad-strip row map, attention windows per utterance."""
+    import torch
+    from qwen3_asr_mlx_amd import AudioEncoder, AudioEncoderConfig
+    enc = AudioEncoder(AudioEncoderConfig())
+    enc.device = torch.device("cpu")
+    pl = enc._plan((3000, 250, 100))
+    assert pl["tok_counts"] == [390, 33, 13] and pl["n_chunks"] == 30 + 3 + 1 and pl["n_tokens"] == 436
+    assert pl["seg_start"].tolist() == [0, 104, 208, 312, 390, 423] and pl["seg_len"].tolist() == [104, 104, 104, 78, 33, 13]
+    rm = pl["row_map"].reshape(-1, 13)
+    assert rm[29].tolist() == list(range(377, 390)) and rm[32].tolist() == list(range(416, 423)) + [-1] * 6
+    assert AudioEncoder._conv_output_length(100) == 13 and AudioEncoder._conv_output_length(50) == 7
+    assert AudioEncoder._block_attention_mask(13, [0, 13]) is None
+    m = AudioEncoder._block_attention_mask(26, [0, 13, 26])                    # reference test_encoder.py:126-159
+    assert m.shape == (1, 1, 26, 26) and float(m[0, 0, 0, 12]) == 0.0 and float(m[0, 0, 0, 13]) < -1e8
+    pe = enc.positional_embedding(13)
+    assert pe.shape == (13, 1024)
+
+
+def test_decode_split_choice():
+    from qwen3_asr_mlx_amd import ops
+    assert ops.pick_splits(4096, 2048) == 8 and ops.pick_splits(12288, 2048) == 4
+    assert ops.pick_splits(2048, 6144) in (12, 24) and ops.pick_splits(151936, 2048) == 1
+    for n, k in ((2048, 2048), (1024, 512), (2048, 1024)):
+        s = ops.pick_splits(n, k)
+        assert k % (s * 256) == 0
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from qwen3_asr_mlx_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.Q3AsrError, match="no CPU fallback"):
+        _lib.load()

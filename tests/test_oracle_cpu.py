@@ -1,0 +1,210 @@
+"""CPU suite (-m "not gpu"): the oracle against the reference-generated golden vectors and the
+reference tests' known answers; the host logic of the product package; the C-ABI's symbol table."""
+import ctypes
+import hashlib
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from signals import signal
+
+GOLD = Path(__file__).parent / "golden"
+ROOT = Path(__file__).parent.parent
+
+
+# ----------------------------------------------------------------------------- mel (pinned to the live reference)
+def test_filterbank_bit_exact_and_quirks():
+    fb = np.load(GOLD / "mel_filterbank.npy")
+    got = oracle.mel_filterbank()
+    assert got.dtype == np.float32 and got.shape == (128, 201)
+    assert np.array_equal(got, fb)
+    assert [i for i in range(128) if not fb[i].any()] == [0, 3, 6, 13]      # four dead rows
+    assert (fb >= 0).all() and abs(float(fb.max()) - 0.02908) < 1e-4
+    assert oracle.mel_filterbank() is oracle.mel_filterbank()               # cached (reference test_audio.py:103-116)
+
+
+def test_mel_bit_exact_against_reference_fixtures():
+    full = np.load(GOLD / "mel_full.npz")
+    for key in full.files:
+        if "_n" in key:
+            x = signal("noise", int(key.split("_n")[1]))
+        else:
+            kind, s = key.split("_")
+            x = signal(kind, int(float(s[:-1]) * 16000))
+        got = oracle.log_mel_spectrogram(x)
+        assert got.dtype == np.float32
+        assert np.array_equal(got, full[key]), key
+    dg = json.loads((GOLD / "mel_digest.json").read_text())
+    for kind in ("tone", "noise"):
+        got = oracle.log_mel_spectrogram(signal(kind, 480000))
+        assert hashlib.sha256(got.reshape(-1).tobytes()).hexdigest() == dg[f"{kind}_30s"]["sha256"]
+    assert np.array_equal(oracle.stft_power(signal("noise", 8000)), np.load(GOLD / "stft_power_noise_0.5s.npy"))
+
+
+def test_mel_reference_test_properties():
+    """reference tests/test_audio.py:49-89."""
+    assert oracle.log_mel_spectrogram(signal("noise", 16000)).shape == (128, 100)
+    assert np.allclose(oracle.log_mel_spectrogram(np.zeros(16000, np.float32)), -1.5, atol=1e-6)
+    m = oracle.log_mel_spectrogram(signal("noise", 16000))
+    assert m.max() - m.min() <= 2.0 + 1e-6                                   # 8 decades / 4
+
+
+# ----------------------------------------------------------------------------- host integer logic
+def test_prompts_exact():
+    pr = json.loads((GOLD / "prompts.json").read_text())
+    for n in (0, 13, 65, 390):
+        assert oracle.build_prompt(n) == pr[f"n{n}_none"]
+        assert oracle.build_prompt(n, [6364]) == pr[f"n{n}_lang"]
+    p = oracle.build_prompt(3, [6364])
+    assert p[:9] == [151644, 8948, 198, 151645, 198, 151644, 872, 198, 151669]      # reference test_tokenizer.py:48-73
+    assert p[9:12] == [151676] * 3 and p[12:] == [151670, 151645, 198, 151644, 77091, 198, 11528, 6364, 151704]
+    assert sorted(oracle.EOS_TOKEN_IDS) == pr["constants"]["EOS_TOKEN_IDS"]
+
+
+def test_split_points_exact():
+    sp = json.loads((GOLD / "split_points.json").read_text())
+    sr = 16000
+    c = sr * 10
+    assert oracle.find_split_points(np.zeros(sr, np.float32), sr * 20, 5 * sr) == sp["short_zeros"] == []
+    assert oracle.find_split_points(np.random.default_rng(0).random(int(c * 2.5)).astype(np.float32), c, 5 * sr) == sp["rng0_2.5chunks"]
+    assert oracle.find_split_points(np.random.default_rng(1).random(c * 3).astype(np.float32), c, 5 * sr) == sp["rng1_3chunks"]
+    s = np.ones(sr * 25, np.float32) * 0.5
+    s[sr * 9: sr * 11] = 0.0
+    got = oracle.find_split_points(s, c, 5 * sr)
+    assert got == sp["silent_window"] and sr * 9 <= got[0] <= sr * 11
+    assert oracle.find_split_points(np.random.default_rng(2).random(sr * 25).astype(np.float32), sr * 5, 2 * sr) == sp["rng2_5x5s"]
+    assert oracle.find_split_points(signal("speechlike", 120 * sr), 30 * sr, 5 * sr) == sp["speechlike_120s_30s"]
+    assert oracle.find_split_points(np.ones(100, np.float32), 50, 10) == sp["tiny_lt_frame"] == []
+
+
+def test_chunk_and_window_bookkeeping():
+    """reference test_encoder.py:65-89,161-164 and SURVEY a6."""
+    assert [oracle.conv_output_length(n) for n in (100, 50, 1, 2, 3)] == [13, 7, 1, 1, 1]
+    for frames, toks in ((100, 13), (300, 39), (250, 33), (3000, 390)):
+        assert sum(oracle.chunk_layout(frames)[1]) == toks
+    assert oracle.window_cu_seqlens(390, 104) == [0, 104, 208, 312, 390]
+    assert oracle.window_cu_seqlens(65, 104) == [0, 65]
+    assert oracle.window_cu_seqlens(208, 104) == [0, 104, 208]
+
+
+# ----------------------------------------------------------------------------- sampling known answers (reference test_generate.py:132-194)
+def test_oracle_sampling_known_answers():
+    assert oracle.sample(torch.tensor([[0.1, 0.5, 0.2, 0.9, 0.3]])) == 3
+    f = oracle.top_k_filter(torch.tensor([0.1, 0.9, 0.5, 0.3, 0.7]), 2)
+    assert torch.isfinite(f).tolist() == [False, True, False, False, True]
+    f = oracle.top_p_filter(torch.tensor([100.0, 0.0, 0.0, 0.0]), 0.99)
+    assert torch.isfinite(f).tolist() == [True, False, False, False]
+    pen = oracle.apply_repetition_penalty(torch.ones(10), [0, 1, 2], 2.0, bf16=False)
+    assert torch.allclose(pen[:3], torch.full((3,), 0.5)) and torch.allclose(pen[3:], torch.ones(7))
+    x = torch.tensor([1.0, 2.0, 3.0, 0.5])
+    assert torch.equal(oracle.apply_repetition_penalty(x, [0, 1], 1.0), x)
+    g = torch.Generator().manual_seed(0)
+    assert all(oracle.sample(torch.tensor([[0.1, 0.5, 0.2, 0.9, 0.3]]), temperature=1.0, top_k=1, generator=g) == 3 for _ in range(10))
+    assert len({oracle.sample(torch.ones(1, 512), temperature=2.0, generator=g) for _ in range(20)}) > 1
+
+
+# ----------------------------------------------------------------------------- decoder properties (reference test_decoder.py)
+def _tiny_decoder(seed=0, layers=2, H=64, nh=4, nkv=2, hd=16, I=128, V=512):
+    g = torch.Generator().manual_seed(seed)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    W = {"embed_tokens.weight": bf(torch.randn(V, H, generator=g) * 0.5), "norm.weight": torch.ones(H)}
+    for i in range(layers):
+        p = f"layers.{i}."
+        W[p + "input_layernorm.weight"] = torch.ones(H)
+        W[p + "post_attention_layernorm.weight"] = torch.ones(H)
+        W[p + "self_attn.q_norm.weight"] = torch.ones(hd)
+        W[p + "self_attn.k_norm.weight"] = torch.ones(hd)
+        for n, o, k in (("self_attn.q_proj", nh * hd, H), ("self_attn.k_proj", nkv * hd, H), ("self_attn.v_proj", nkv * hd, H),
+                        ("self_attn.o_proj", H, nh * hd), ("mlp.gate_proj", I, H), ("mlp.up_proj", I, H), ("mlp.down_proj", H, I)):
+            W[p + n + ".weight"] = bf(torch.randn(o, k, generator=g) * (k ** -0.5))
+    return oracle.DecoderOracle(W, nh, nkv, hd, 1e-6, 1e6)
+
+
+def test_rmsnorm_formula_and_rope_properties():
+    import oracle.decoder as od
+    x = torch.randn(3, 5, 64)
+    ref = x / torch.sqrt((x ** 2).mean(-1, keepdim=True) + 1e-6)
+    assert torch.allclose(od.rms_norm(x, torch.ones(64), 1e-6), od.bf(ref), atol=1e-4)       # test_decoder.py:77-89
+    q = od.bf(torch.randn(2, 4, 6, 16))
+    r = od.rope(q, torch.arange(6), 1e6)
+    assert r.shape == q.shape
+    assert torch.allclose(r.norm(dim=-1), q.norm(dim=-1), rtol=2e-2)                           # norm preserving (:107-126)
+    one = od.rope(q[:, :, 1:2], torch.tensor([1]), 1e6)
+    assert torch.equal(one, r[:, :, 1:2])                                                      # offset equivalence (:128-149)
+    assert torch.equal(od.rope(q[:, :, :1], torch.tensor([0]), 1e6), q[:, :, :1])             # position 0 is identity
+    qn = od.rms_norm(torch.randn(7, 4, 16) * 5, torch.ones(16), 1e-6)
+    assert torch.allclose((qn ** 2).mean(-1).sqrt(), torch.ones(7, 4), atol=2e-2)             # QK-norm unit RMS (:157-173)
+
+
+def test_cached_decode_equals_full_context():
+    dec = _tiny_decoder()
+    ids = [5, 17, 300, 42, 7, 99]
+    full = dec.forward(dec.embed(ids), last_only=False)
+    assert full.shape == (6, 512)                                                              # logits (T, V) (:208-226)
+    dec.reset()
+    dec.forward(dec.embed(ids[:-1]))
+    assert dec.k[0].shape == (2, 5, 16) and dec.offset == 5                                    # cache growth (:254-283)
+    step = dec.forward(dec.embed(ids[-1:]))
+    assert dec.k[0].shape == (2, 6, 16)
+    assert torch.allclose(step[-1], full[-1], atol=0.15, rtol=0.05)                           # bf16 re-rounding only (:285-312)
+    # tied head: logits = norm(h) @ embed^T (:228-247) -- with identity-free check on shapes and finiteness
+    assert torch.isfinite(full).all()
+
+
+def test_prepare_inputs_semantics():
+    """reference test_generate.py:63-124."""
+    E = torch.arange(20 * 4, dtype=torch.float32).reshape(20, 4)
+    pad = 7
+    out = oracle.prepare_inputs(torch.zeros(0, 4), [1, 2, 3, 4], E, audio_pad_id=pad)
+    assert torch.equal(out, E[[1, 2, 3, 4]])
+    out = oracle.prepare_inputs(torch.full((2, 4), 9.0), [1, pad, pad, 2], E, audio_pad_id=pad)
+    assert torch.equal(out[1:3], torch.full((2, 4), 9.0)) and torch.equal(out[0], E[1]) and torch.equal(out[3], E[2])
+    with pytest.raises(ValueError, match="does not match"):
+        oracle.prepare_inputs(torch.zeros(3, 4), [1, pad, pad], E, audio_pad_id=pad)
+
+
+def test_generate_loop_bounds_and_eos():
+    """reference test_generate.py:201-242: <= max_tokens ids, list[int], EOS kept then stop."""
+    dec = _tiny_decoder(V=512)
+    out = oracle.generate(dec, torch.zeros(0, 64), [1, 2, 3], max_tokens=5)
+    assert isinstance(out, list) and len(out) == 5 and all(isinstance(t, int) for t in out)
+    assert oracle.generate(dec, torch.zeros(0, 64), [1, 2, 3], max_tokens=1) == out[:1]
+    out2 = oracle.generate(dec, torch.zeros(0, 64), [1, 2, 3], max_tokens=5)
+    assert out2 == out                                                                         # greedy determinism
+
+
+def test_encoder_oracle_shapes_and_block_locality():
+    """Conv stem token counts and the block-diagonal window: changing audio in one 104-token window
+    must not change another window's output beyond the shared conv chunks (encoder.py:210-229)."""
+    g = torch.Generator().manual_seed(1)
+    d, C1, ffn, out_dim, heads = 64, 8, 128, 32, 1
+    W = {"conv2d1.weight": torch.randn(C1, 3, 3, 1, generator=g) * 0.3, "conv2d1.bias": torch.zeros(C1),
+         "conv2d2.weight": torch.randn(C1, 3, 3, C1, generator=g) * 0.1, "conv2d2.bias": torch.zeros(C1),
+         "conv2d3.weight": torch.randn(C1, 3, 3, C1, generator=g) * 0.1, "conv2d3.bias": torch.zeros(C1),
+         "conv_out.weight": torch.randn(d, C1 * 16, generator=g) * 0.1,
+         "ln_post.weight": torch.ones(d), "ln_post.bias": torch.zeros(d),
+         "proj1.weight": torch.randn(d, d, generator=g) * 0.1, "proj1.bias": torch.zeros(d),
+         "proj2.weight": torch.randn(out_dim, d, generator=g) * 0.1, "proj2.bias": torch.zeros(out_dim)}
+    p = "layers.0."
+    for n, o, k in (("self_attn.q_proj", d, d), ("self_attn.k_proj", d, d), ("self_attn.v_proj", d, d),
+                    ("self_attn.out_proj", d, d), ("fc1", ffn, d), ("fc2", d, ffn)):
+        W[p + n + ".weight"] = torch.randn(o, k, generator=g) * 0.1
+        W[p + n + ".bias"] = torch.zeros(o)
+    for n in ("self_attn_layer_norm", "final_layer_norm"):
+        W[p + n + ".weight"], W[p + n + ".bias"] = torch.ones(d), torch.zeros(d)
+    mel = torch.randn(128, 1000, generator=g)
+    out = oracle.encoder_forward(mel, W, n_heads=heads)
+    assert out.shape == (130, out_dim)
+    mel2 = mel.clone()
+    mel2[:, 900:] += 1.0                                    # only the last chunk (window 2: tokens 104..129)
+    out2 = oracle.encoder_forward(mel2, W, n_heads=heads)
+    assert torch.equal(out[:104], out2[:104]) and not torch.allclose(out[117:], out2[117:])
+    assert oracle.encoder_forward(mel[:, :250], W, n_heads=heads).shape[0] == 33
+    pe = oracle.sinusoid_table(1500, 64)
+    assert pe.shape == (1500, 64) and torch.equal(pe[:13], oracle.sinusoid_table(13, 64))     # test_encoder.py:171-198
+    assert torch.equal(pe[0], torch.cat([torch.zeros(32), torch.ones(32)]))

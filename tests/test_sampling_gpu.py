@@ -1,0 +1,126 @@
+"""Token selection on the device: the reference's sampling known-answers (tests/test_generate.py
+:132-194) restated against q3asr_sample_step, plus tie-break, penalty rounding, top-k/top-p support
+sets and a distribution check against the oracle's filtered softmax."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_greedy_returns_argmax(dev):
+    from qwen3_asr_mlx_amd import sample
+    assert sample(torch.tensor([[0.1, 0.5, 0.2, 0.9, 0.3]]), temperature=0.0) == 3
+
+
+def test_greedy_lowest_index_on_ties_and_big_vocab(dev):
+    from qwen3_asr_mlx_amd import sample
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(151936, generator=g).to(torch.bfloat16).float()
+    x[[777, 150000, 90001]] = 7.0                     # exact three-way tie at the top
+    assert sample(x, temperature=0.0) == 777
+    x[5] = 7.0
+    assert sample(x, temperature=0.0) == 5
+    assert sample(x, temperature=0.0) == int(torch.argmax(x))
+
+
+def test_temperature_sampling_is_stochastic(dev):
+    from qwen3_asr_mlx_amd import sample
+    logits = torch.ones(1, 512)
+    assert len({sample(logits, temperature=2.0) for _ in range(20)}) > 1
+
+
+def test_top_k_1_always_argmax(dev):
+    from qwen3_asr_mlx_amd import sample
+    logits = torch.tensor([[0.1, 0.5, 0.2, 0.9, 0.3]])
+    assert all(sample(logits, temperature=1.0, top_k=1) == 3 for _ in range(10))
+
+
+def test_top_k_keeps_exactly_k_candidates(dev):
+    from qwen3_asr_mlx_amd import sample
+    logits = torch.tensor([0.1, 0.9, 0.5, 0.3, 0.7])
+    seen = {sample(logits, temperature=1.0, top_k=2, seed=s) for s in range(200)}
+    assert seen == {1, 4}
+
+
+def test_top_k_keeps_ties_at_threshold(dev):
+    from qwen3_asr_mlx_amd import sample
+    logits = torch.tensor([0.5, 2.0, 1.0, 1.0, 1.0, -3.0])       # k=2 -> threshold 1.0, ties kept (generate.py:141)
+    seen = {sample(logits, temperature=1.0, top_k=2, seed=s) for s in range(400)}
+    assert seen == {1, 2, 3, 4}
+
+
+def test_top_p_restricts_to_nucleus(dev):
+    from qwen3_asr_mlx_amd import sample
+    logits = torch.tensor([100.0, 0.0, 0.0, 0.0])
+    assert {sample(logits, temperature=1.0, top_p=0.99, seed=s) for s in range(50)} == {0}
+
+
+def test_top_p_support_matches_oracle(dev):
+    import oracle
+    from qwen3_asr_mlx_amd import sample
+    logits = torch.tensor([2.0, 1.5, 1.5, 1.0, 0.5, 0.0, -1.0, -2.0]).to(torch.bfloat16).float()
+    for top_p in (0.3, 0.5, 0.7, 0.9):
+        keep = torch.isfinite(oracle.top_p_filter(logits, top_p)).nonzero().flatten().tolist()
+        seen = {sample(logits, temperature=1.0, top_p=top_p, seed=s) for s in range(600)}
+        assert seen == set(keep), (top_p, seen, keep)
+
+
+def test_repetition_penalty_semantics(dev):
+    """reference test_generate.py:176-194: listed ids only, l>0 -> l/p, l<0 -> l*p; p=1 identity;
+    p is rounded to bf16 (1.2 -> 1.203125) like the weakly-typed MLX scalar."""
+    from qwen3_asr_mlx_amd import sample
+    # token 0 leads unpenalised; with penalty 2.0 on [0] it drops to 1.5 < 2.0
+    logits = torch.tensor([3.0, 2.0, 1.0, -1.0])
+    assert sample(logits, repetition_penalty=1.0, recent_tokens=[0]) == 0
+    assert sample(logits, repetition_penalty=2.0, recent_tokens=[0]) == 1
+    assert sample(logits, repetition_penalty=2.0, recent_tokens=[0, 0, 0]) == 1          # unique ids: applied once
+    assert sample(logits, repetition_penalty=2.0, recent_tokens=None) == 0
+    # negative logits are multiplied: -1 * 2 = -2 < -1.5
+    neg = torch.tensor([-1.0, -1.5, -4.0, -8.0])
+    assert sample(neg, repetition_penalty=2.0, recent_tokens=[0]) == 1
+    # bf16 rounding of the scalar: 1.2 -> 1.203125; 2.40625/1.203125 = 2.0 exactly
+    tie = torch.tensor([2.40625, 2.0, 0.0, 0.0])
+    assert sample(tie, repetition_penalty=1.2, recent_tokens=[0]) == 0                    # 2.0 vs 2.0 -> lowest index
+    tie2 = torch.tensor([2.0, 2.40625, 0.0, 0.0])
+    assert sample(tie2, repetition_penalty=1.2, recent_tokens=[1]) == 0
+    # out-of-range ids are ignored
+    assert sample(logits, repetition_penalty=2.0, recent_tokens=[99999, -5]) == 0
+
+
+def test_sampling_distribution_matches_filtered_softmax(dev):
+    import oracle
+    from qwen3_asr_mlx_amd import sample
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(64, generator=g) * 2).to(torch.bfloat16).float()
+    T, k, p = 0.7, 20, 0.9
+    x = (logits / torch.tensor(T).to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    probs = torch.softmax(oracle.top_p_filter(oracle.top_k_filter(x, k), p), dim=-1).numpy()
+    n = 4000
+    counts = np.bincount([sample(logits, temperature=T, top_k=k, top_p=p, seed=s) for s in range(n)], minlength=64)
+    assert set(np.nonzero(counts)[0]) <= set(np.nonzero(probs)[0])
+    # total-variation distance of an n-sample empirical law from its source is ~ sqrt(K/n)
+    assert 0.5 * np.abs(counts / n - probs).sum() < 0.06
+
+
+def test_bookkeeping_eos_budget_and_finished(dev):
+    from qwen3_asr_mlx_amd import ops
+    from qwen3_asr_mlx_amd.tokenizer import IM_END_TOKEN_ID, ENDOFTEXT_TOKEN_ID
+    V, B = 1024, 3
+    logits = torch.zeros((B, V), dtype=torch.bfloat16, device=dev)
+    logits[0, 5] = 3.0
+    logits[1, 7] = 3.0
+    logits[2, 9] = 3.0
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    out = torch.full((B, 4), -1, dtype=torch.int32, device=dev)
+    n_gen, fin, cur, pos, mx = i32([0, 0, 0]), i32([0, 0, 1]), i32([0, 0, 42]), i32([10, 20, 30]), i32([4, 1, 4])
+
+    def step(eos0=5, eos1=ENDOFTEXT_TOKEN_ID):
+        ops.call("q3asr_sample_step", ops.ptr(logits), V, B, V, ops.ptr(out), 4, ops.ptr(n_gen), ops.ptr(fin), ops.ptr(cur),
+                 ops.ptr(pos), ops.ptr(mx), 0.0, 1.0, 0, 1.0, 100, 0, eos0, eos1, ops.sp())
+    step()
+    assert out[0, 0].item() == 5 and fin[0].item() == 1 and pos[0].item() == 10      # EOS recorded, then stop
+    assert out[1, 0].item() == 7 and fin[1].item() == 1                               # budget of 1 reached
+    assert out[2, 0].item() == -1 and cur[2].item() == 42 and n_gen[2].item() == 0    # already finished: untouched
+    step()
+    assert n_gen.tolist() == [1, 1, 0] and out[0, 1].item() == -1
