@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Headline benchmark: real-time factor (audio-seconds / wall-seconds) of the Qwen3-ASR-1.7B hot
+path on 30 s clips, batch 32 per GPU (BASELINE.json configs[2]; configs[3] = the same per GPU on 8).
+
+A step = one pass of the hot path over one batch already resident in HBM: log-mel -> conv stem +
+24-layer encoder -> prompt merge -> 28-layer prefill -> N_dec-1 hipGraph-replayed decode steps with
+on-device greedy sampling (repetition penalty 1.2, the API default) -> token ids on the host.
+Weights are synthetic (seeded N(0, 0.02^2), bf16, reference checkpoint layout); random weights never
+emit EOS, so every sequence decodes exactly N_dec tokens.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+N > 1: rank 0 owns the request (32*N clips resident on its GPU), scatters audio and gathers token ids
+with torch.distributed (RCCL over xGMI); weights are replicated; weak scaling.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+_T0 = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    """Progress on stderr (stdout carries only the JSON line)."""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def synth_clip(i: int, n: int) -> np.ndarray:
+    from signals import signal
+    return signal("speechlike", n, seed=1234 + i)
+
+
+def decode_bytes_per_launch(cfg, B: int):
+    """Algorithmic bytes of one skinny-GEMM launch = weight bytes (2*N*K); list over one decode step."""
+    t = cfg.text_decoder
+    H, I = t.hidden_size, t.intermediate_size
+    qd = t.num_attention_heads * t.head_dim
+    qkvd = (t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim
+    per_layer = [2 * qkvd * H, 2 * H * qd, 2 * 2 * I * H, 2 * H * I]
+    return per_layer * t.num_hidden_layers + [2 * t.vocab_size * H]
+
+
+def cpu_baseline(cfg, state, clip, n_dec_sample: int, n_dec_full: int):
+    """The oracle (CPU restatement of the reference algorithm, oracle/) timed on this host's cores on
+    ONE clip with a short decode, extrapolated to n_dec_full tokens."""
+    import torch
+    import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads")
+    Wd = {k[len("model."):]: v.float().cpu() for k, v in state.items() if k.startswith("model.")}
+    We = {k[len("audio_tower."):]: v.float().cpu() for k, v in state.items() if k.startswith("audio_tower.")}
+    a, t = cfg.audio_encoder, cfg.text_decoder
+    t0 = time.perf_counter()
+    mel = oracle.log_mel_spectrogram(clip)
+    t_mel = time.perf_counter() - t0
+    log(f"cpu_baseline: mel {t_mel:.2f}s")
+    t0 = time.perf_counter()
+    feats = oracle.encoder_forward(torch.from_numpy(mel), We, a.encoder_attention_heads, a.n_window, a.n_window_infer)
+    t_enc = time.perf_counter() - t0
+    log(f"cpu_baseline: encoder {t_enc:.2f}s")
+    dec = oracle.DecoderOracle(Wd, t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.rms_norm_eps, t.rope_theta)
+    prompt = oracle.build_prompt(feats.shape[0], [6364])
+    t0 = time.perf_counter()
+    emb = oracle.prepare_inputs(feats, prompt, Wd["embed_tokens.weight"])
+    logits = dec.forward(emb)
+    t_pre = time.perf_counter() - t0
+    log(f"cpu_baseline: prefill {t_pre:.2f}s")
+    tok = oracle.sample(logits[-1])
+    out = [tok]
+    t0 = time.perf_counter()
+    for _ in range(n_dec_sample):
+        logits = dec.forward(dec.embed([tok]))
+        tok = oracle.sample(logits[-1], repetition_penalty=1.2, recent_tokens=out[-100:])
+        out.append(tok)
+    t_tok = (time.perf_counter() - t0) / n_dec_sample
+    total = t_mel + t_enc + t_pre + (n_dec_full - 1) * t_tok
+    secs = len(clip) / 16000.0
+    return {
+        "value": secs / total, "unit": "audio-s/wall-s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/ (numpy mel + torch-CPU fp32 encoder/decoder, batch 1) on 1 clip of {secs:g} s: mel {t_mel:.2f} s, "
+                   f"encoder {t_enc:.2f} s, prefill {t_pre:.2f} s, {n_dec_sample} decode steps at {t_tok:.3f} s/token "
+                   f"extrapolated to {n_dec_full} tokens"),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--clip-seconds", type=float, default=30.0)
+    ap.add_argument("--ndec", type=int, default=128, help="decoded tokens per utterance")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import _lib, synth
+    from qwen3_asr_mlx_amd.config import ModelConfig
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = ModelConfig()                                     # Qwen3-ASR-1.7B defaults (reference config.py)
+    log("building synthetic 1.7B weights on the device")
+    state = synth.random_state(cfg, seed=0, device=dev)
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
+    log("model ready")
+    model.use_graph = not args.no_graph
+    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
+        del state
+    B, n = args.batch, int(args.clip_seconds * 16000)
+    budgets = [args.ndec] * B
+
+    # ---- request: resident in HBM before the timed region
+    if world == 1:
+        audio, lens_dev, lens = q.audio.pack_audio([synth_clip(i, n) for i in range(B)], dev)
+        torch.cuda.synchronize()
+
+        def step():
+            return model.generate_tokens_device(audio, lens_dev, lens, budgets, "English", repetition_penalty=1.2)
+    else:
+        lens = [n] * B
+        lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+        mine = torch.empty((B, n), dtype=torch.float32, device=dev)
+        parts = None
+        if rank == 0:
+            parts = [q.audio.pack_audio([synth_clip(r * B + i, n) for i in range(B)], dev)[0] for r in range(world)]
+        tok_buf = torch.empty((B, args.ndec), dtype=torch.int32, device=dev)
+        gathered = [torch.empty_like(tok_buf) for _ in range(world)] if rank == 0 else None
+
+        def step():
+            dist.scatter(mine, parts, src=0)                                  # RCCL over xGMI: 1.92 MB per clip
+            toks = model.generate_tokens_device(mine, lens_dev, lens, budgets, "English", repetition_penalty=1.2)
+            tok_buf.copy_(torch.tensor(toks, dtype=torch.int32))
+            dist.gather(tok_buf, gathered, dst=0)
+            return toks
+
+    for i in range(args.warmup):
+        w0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i}: {time.perf_counter() - w0:.3f}s")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    per_step = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s0 = time.perf_counter()
+        toks = step()
+        torch.cuda.synchronize()
+        per_step.append(time.perf_counter() - s0)
+        log(f"timed step: {per_step[-1]:.3f}s")
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert all(len(t) == args.ndec for t in toks)
+
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+
+    audio_s = world * B * args.clip_seconds * args.steps
+    line = {
+        "metric": "real-time factor (audio-sec/wall-sec), Qwen3-ASR-1.7B bf16 30s clips",
+        "value": audio_s / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Qwen3-ASR-1.7B bf16, batch={B}/GPU, {args.clip_seconds:g} s clips, greedy (repetition_penalty 1.2), "
+                               f"{args.ndec} decoded tokens/clip, hipGraph decode" + ("" if world == 1 else f", {world}-GPU DP over RCCL"),
+                   "batch_per_gpu": B, "clip_seconds": args.clip_seconds, "decoded_tokens": args.ndec,
+                   "weights": "synthetic seeded N(0,0.02^2) bf16", "graph": not args.no_graph},
+        "p50_latency_ms": 1e3 * float(np.median(per_step)),
+    }
+
+    if world == 1:
+        # ---- roofline of the dominant kernel (decode weight streaming: skinny_gemm_kernel), HIP events on
+        # the launch stream around every launch of instrumented eager decode steps on the same state
+        from qwen3_asr_mlx_amd.generate import generate_batch
+        nsteps = 4
+        feats_len = None
+        prof = {"names": {"q3asr_skinny_gemm"}, "stream": C.c_void_p(torch.cuda.current_stream().cuda_stream), "events": []}
+        model.use_graph = False
+        model.generate_tokens_device(audio, lens_dev, lens, [2] * B, "English", repetition_penalty=1.2)   # code warm
+        _lib.PROFILE = prof
+        model.generate_tokens_device(audio, lens_dev, lens, [1 + nsteps] * B, "English", repetition_penalty=1.2)
+        _lib.PROFILE = None
+        torch.cuda.synchronize()
+        rec = _lib.drain_profile(prof)
+        log(f"roofline leg: {len(rec)} skinny_gemm launches timed")
+        model.use_graph = not args.no_graph
+        per_launch = decode_bytes_per_launch(cfg, B)
+        # drop the prefill's single lm_head launch (first record), keep whole decode steps
+        rec = rec[1:]
+        n_per_step = len(per_launch)
+        rec = rec[: (len(rec) // n_per_step) * n_per_step]
+        total_ms = sum(r[1] for r in rec)
+        total_bytes = sum(per_launch) * (len(rec) // n_per_step)
+        avg_ms = total_ms / max(1, len(rec))
+        achieved = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+        traffic = None
+        pmc = ROOT / "profiles" / "r01_pmc_summary.json"
+        if pmc.exists():
+            traffic = json.loads(pmc.read_text()).get("skinny_gemm_hbm_bytes_per_launch")
+        line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                            "kernel": "skinny_gemm_kernel<2> (decode weight streaming)",
+                            "launches_measured": len(rec), "avg_launch_us": 1e3 * avg_ms,
+                            "bytes_per_launch": sum(per_launch) / n_per_step}
+        if not args.no_cpu_baseline:
+            model.close()
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline(cfg, state, synth_clip(0, n), 8, args.ndec)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

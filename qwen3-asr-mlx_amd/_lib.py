@@ -77,8 +77,36 @@ def check(rc: int, what: str = "") -> None:
         raise Q3AsrError(f"{what}: {msg} (rc={rc})")
 
 
+PROFILE = None          # bench.py: {"names": set, "stream": c_void_p, "events": [(name, start, stop)]}
+
+
 def call(name: str, *args) -> None:
-    check(getattr(load(), name)(*args), name)
+    lib = load()
+    prof = PROFILE
+    if prof is not None and name in prof["names"]:
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        lib.q3asr_event_create(C.byref(e0))
+        lib.q3asr_event_create(C.byref(e1))
+        lib.q3asr_event_record(e0, prof["stream"])
+        check(getattr(lib, name)(*args), name)
+        lib.q3asr_event_record(e1, prof["stream"])
+        prof["events"].append((name, e0, e1, args))
+        return
+    check(getattr(lib, name)(*args), name)
+
+
+def drain_profile(prof) -> list:
+    """[(name, ms, args)] for the recorded calls; destroys the events."""
+    lib = load()
+    out = []
+    for name, e0, e1, args in prof["events"]:
+        ms = C.c_float()
+        check(lib.q3asr_event_elapsed_ms(e0, e1, C.byref(ms)), "event_elapsed")
+        out.append((name, float(ms.value), args))
+        lib.q3asr_event_destroy(e0)
+        lib.q3asr_event_destroy(e1)
+    prof["events"].clear()
+    return out
 
 
 def ptr(t):

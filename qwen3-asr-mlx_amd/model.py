@@ -230,8 +230,18 @@ class Qwen3ASR:
         if self._encoder is None or self._decoder is None:
             raise TypeError("'NoneType' object is not callable")             # use after close(), as the reference
         dev = self._decoder.device
-        fe = get_frontend(dev)
         audio, lens_dev, lens = pack_audio(batch, dev)
+        return self.generate_tokens_device(audio, lens_dev, lens, max_tokens, lang, temperature, top_p, top_k,
+                                           repetition_penalty, repetition_context_size)
+
+    def generate_tokens_device(self, audio, lens_dev, lens: Sequence[int], max_tokens: Sequence[int], lang: str,
+                               temperature=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2,
+                               repetition_context_size=100) -> list[list[int]]:
+        """Same, with the padded fp32 audio [B][Lmax] and int32 lengths already resident in HBM."""
+        if self._encoder is None or self._decoder is None:
+            raise TypeError("'NoneType' object is not callable")
+        dev = self._decoder.device
+        fe = get_frontend(dev)
         mel, n_frames = fe(audio, lens_dev, lens)
         feats, tok_counts = self._encoder.forward_batch(mel, n_frames)
         lang_ids = self._tokenizer.encode(f" {lang}")
