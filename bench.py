@@ -59,7 +59,8 @@ def cpu_baseline(cfg, state, clip, n_dec_sample: int, n_dec_full: int):
     ONE clip with a short decode, extrapolated to n_dec_full tokens."""
     import torch
     import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # threads actually used: the affinity mask, capped at the 16-core share a one-GPU box gets
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     log(f"cpu_baseline: {cores} threads")
     Wd = {k[len("model."):]: v.float().cpu() for k, v in state.items() if k.startswith("model.")}

@@ -205,3 +205,47 @@ def test_from_pretrained_round_trip_and_close(dev, tmp_path):
         model.transcribe(signal("noise", 16000))
     with pytest.raises(FileNotFoundError):
         q.Tokenizer(tmp_path)                                              # tokenizer.py:149-152
+
+
+# ----------------------------------------------------------------------------- full-size model (BASELINE.json configs[0]/[1])
+@pytest.fixture(scope="module")
+def full(dev):
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    from qwen3_asr_mlx_amd.config import ModelConfig
+    cfg = ModelConfig()
+    state = synth.random_state(cfg, seed=0, device=dev)
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
+    return cfg, state, model
+
+
+def test_full_size_5s_clip_greedy_matches_oracle(dev, full):
+    """Qwen3-ASR-1.7B shapes, single 5 s clip, greedy with the API-default penalty: encoder features,
+    first-token logits and 12 decoded tokens against the CPU oracle (same synthetic weights)."""
+    import oracle
+    import qwen3_asr_mlx_amd as q
+    cfg, state, model = full
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    x = signal("speechlike", 80000)
+    cpu_state = {k: v.float().cpu() for k, v in state.items()}
+    enc, dec = _oracle_parts(cfg, cpu_state)
+    feats_ref = enc(oracle.log_mel_spectrogram(x))
+    feats = model._encoder(q.log_mel_spectrogram(x))[0].cpu()
+    assert feats.shape == feats_ref.shape == (65, 2048)
+    # 24 layers deep: bf16 re-rounding noise accumulates; outputs are O(1)
+    assert (feats - feats_ref).abs().max() < 0.08 and (feats - feats_ref).abs().mean() < 0.01
+    toks = model.generate_tokens([x], [12], "English", repetition_penalty=1.2)[0]
+    exact = _check_tokens_against_oracle(dec, feats_ref, toks, 1.2, tol=0.12)
+    assert exact >= 9
+    assert model.generate_tokens([x], [12], "English", repetition_penalty=1.2)[0] == toks
+
+
+def test_full_size_batch_invariance_30s(dev, full):
+    """Size-independent property at the benchmark shape: utterance results do not depend on batch
+    mates or batch position (B=4 of 30 s clips vs each alone), graph replay == eager."""
+    cfg, state, model = full
+    xs = [signal("speechlike", 480000, seed=s) for s in (11, 12, 13, 14)]
+    batched = model.generate_tokens(xs, [10] * 4, "English")
+    for i in (0, 3):
+        assert model.generate_tokens([xs[i]], [10], "English")[0] == batched[i]
+    assert model.generate_tokens(xs[::-1], [10] * 4, "English") == batched[::-1]
