@@ -208,39 +208,39 @@ def main() -> None:
     }
 
     if world == 1:
-        # ---- roofline of the dominant kernel (decode weight streaming: skinny_gemm_kernel), HIP events on
-        # the launch stream around every launch of instrumented eager decode steps on the same state
-        from qwen3_asr_mlx_amd.generate import generate_batch
-        nsteps = 4
-        feats_len = None
-        prof = {"names": {"q3asr_skinny_gemm"}, "stream": C.c_void_p(torch.cuda.current_stream().cuda_stream), "events": []}
-        model.use_graph = False
-        model.generate_tokens_device(audio, lens_dev, lens, [2] * B, "English", repetition_penalty=1.2)   # code warm
-        _lib.PROFILE = prof
-        model.generate_tokens_device(audio, lens_dev, lens, [1 + nsteps] * B, "English", repetition_penalty=1.2)
-        _lib.PROFILE = None
-        torch.cuda.synchronize()
-        rec = _lib.drain_profile(prof)
-        log(f"roofline leg: {len(rec)} skinny_gemm launches timed")
-        model.use_graph = not args.no_graph
+        # ---- roofline of the dominant kernel (decode weight streaming: skinny3_kernel).  HIP events on the
+        # launch stream around R back-to-back "GEMM-only" decode steps: exactly the 113 weight-streaming
+        # launches of a step (4 per layer over all 28 layers' distinct weights, so 3.4 GB per step and no
+        # cache reuse between launches, + the tied head), same operands and split factors as the timed region.
+        dec = model._decoder
+        ws = dec.workspace(B, args.ndec)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+        lib = _lib.load()
+        lib.q3asr_event_create(C.byref(e0))
+        lib.q3asr_event_create(C.byref(e1))
+        dec.gemm_only_step(ws)                                           # warm
+        R = 20
+        _lib.check(lib.q3asr_event_record(e0, stream), "event_record")
+        launches = 0
+        for _ in range(R):
+            launches += dec.gemm_only_step(ws)
+        _lib.check(lib.q3asr_event_record(e1, stream), "event_record")
+        _lib.check(lib.q3asr_event_elapsed_ms(e0, e1, C.byref(ms)), "event_elapsed")
         per_launch = decode_bytes_per_launch(cfg, B)
-        # drop the prefill's single lm_head launch (first record), keep whole decode steps
-        rec = rec[1:]
-        n_per_step = len(per_launch)
-        rec = rec[: (len(rec) // n_per_step) * n_per_step]
-        total_ms = sum(r[1] for r in rec)
-        total_bytes = sum(per_launch) * (len(rec) // n_per_step)
-        avg_ms = total_ms / max(1, len(rec))
-        achieved = total_bytes / (total_ms * 1e-3) / 1e9 if total_ms > 0 else 0.0
+        total_bytes = sum(per_launch) * R
+        avg_ms = ms.value / launches
+        achieved = total_bytes / (ms.value * 1e-3) / 1e9
+        log(f"roofline leg: {launches} skinny3 launches in {ms.value:.2f} ms")
         traffic = None
         pmc = ROOT / "profiles" / "r01_pmc_summary.json"
         if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get("skinny_gemm_hbm_bytes_per_launch")
+            traffic = json.loads(pmc.read_text()).get("skinny3_hbm_bytes_per_launch")
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                            "kernel": "skinny_gemm_kernel<2> (decode weight streaming)",
-                            "launches_measured": len(rec), "avg_launch_us": 1e3 * avg_ms,
-                            "bytes_per_launch": sum(per_launch) / n_per_step}
+                            "kernel": "skinny3_kernel (decode weight streaming, all shapes of one step)",
+                            "launches_measured": launches, "avg_launch_us": 1e3 * avg_ms,
+                            "bytes_per_launch": sum(per_launch) / len(per_launch)}
         if not args.no_cpu_baseline:
             model.close()
             torch.cuda.empty_cache()

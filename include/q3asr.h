@@ -97,6 +97,28 @@ int q3asr_skinny_gemm(const void* X, int64_t ldx, int M, const void* W, int64_t 
 int q3asr_slab_residual_rmsnorm(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
                                 const void* w, void* x_out, int M, int N, float eps, void* stream);
 int q3asr_slab_swiglu(const float* slab, int n_slabs, int64_t slab_stride, void* act, int M, int I, void* stream);
+/* ---- streaming layouts of the graph-captured decode step (csrc/decode.hip) ---------------------
+ * W16 [N/16][K/32][64][8]: lane (g=lane>>4, li=lane&15) holds W[16rt+li][32ks+8g+j];
+ * X16 [K/32][MT][64][8]:   lane holds X[16mt+li][32ks+8g+j], MT = 1/2/4 for M <= 16/32/64.
+ * skinny3: one wave per 16-row weight tile and K slice, global -> MFMA, no LDS.
+ *   epi 0: fp32 slabs [n_splits][M][N]; epi 1: bf16 row-major out [M][ldo]; epi 2: SwiGLU of
+ *   (gate tile, up tile) pairs -> bf16 X16 (K' = N/2).  waves_per_wg, tiles_per_wave in {1,2,4};
+ *   wg_ksplit != 0: the waves of a workgroup split its K slice and reduce through LDS (fixed order). */
+int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, int N, int K, int n_splits, int epi,
+                       int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out, int64_t ldo,
+                       void* stream);
+/* h = bf16(h + bf16(sum slabs)); x16 = RMSNorm(h)*w in X16 layout (decoder.py:191-196,189,251) */
+int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
+                           const void* w, void* x16, int M, int N, float eps, void* stream);
+/* h = E[tok[m]] (tok NULL: h = E[m]); x16 = RMSNorm(h)*w (generate.py:294 + decoder.py:189) */
+int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_out, const void* w, void* x16, int M, int N,
+                         float eps, void* stream);
+/* decode attention with decoder.py:144-156 (QK-RMSNorm, RoPE, cache append) fused into its prologue;
+ * input: the qkv projection as n_slabs fp32 slabs [n_slabs][B][ld]; output att in X16 layout. */
+int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_slabs, int64_t slab_stride, const void* qn_w,
+                            const void* kn_w, const float* inv_freq, float eps, void* k_cache, void* v_cache,
+                            const int32_t* pos, void* out16, int B, int nh, int nkv, int head_dim, int Lmax,
+                            float scale, void* stream);
 int q3asr_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
                       int B, int nh, int nkv, int head_dim, int Lmax, float scale, void* stream);
 

@@ -1,0 +1,450 @@
+// Decode step, HBM-bound kernels in their streaming layouts (reference generate.py:289-313 ->
+// decoder.py:219-253 at T = 1, batch M <= 64).
+//
+// Layouts (static weights are re-tiled once at load; activations are written in this form by their
+// producer kernels, so every wave-level load below is ONE contiguous, fully used 1 KiB):
+//   W16  [N/16][K/32][64 lanes][8]   lane (g = lane>>4, li = lane&15) holds W[16 rt + li][32 ks + 8 g + j]
+//                                    -> a row tile's K range is one contiguous stream (K/32 KiB);
+//   X16  [K/32][MT][64 lanes][8]     lane holds X[16 mt + li][32 ks + 8 g + j], MT = ceil(M/16).
+// These are exactly the A / B operand fragments of v_mfma_f32_16x16x32_bf16, so the GEMM is
+// global_load_dwordx4 -> MFMA with no LDS and no barrier; X16 (128 KB at K = 2048) stays in L1/L2.
+#include "common.h"
+
+__device__ __forceinline__ long x16_index(int m, int k, int MT) {      // element offset of X[m][k]
+    return ((long)(k >> 5) * MT + (m >> 4)) * 512 + ((((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
+}
+
+// ---------------------------------------------------------------------------
+// skinny3: C[M, N] = X . W^T.  One wave per RT consecutive 16-row weight tiles and one K slice: the
+// X16 fragments it loads (L1/L2) are reused for RT weight tiles, so activation loads are 1/RT of the
+// weight loads; RT*G KiB of weights are in flight per wave (nontemporal: each byte is used once).
+// A workgroup is a bundle of waves that either own different tiles of the same K slice
+// (grid (ceil(N/16/RT/waves), S)) or -- wg_ksplit -- split the K slice of ONE tile group among
+// themselves and add their partial sums through LDS in fixed wave order (grid (N/16/RT, S)); the
+// latter gives complete sums per workgroup, which the SwiGLU epilogue needs, with the same
+// parallelism as a split-K launch.
+//   EPI 0: fp32 slab [S][M][N] (consumer adds slabs in fixed order)
+//   EPI 1: bf16 row-major out [M][ldo]                      (tied lm_head -> logits)
+//   EPI 2: SwiGLU of the (gate tile, up tile) pairs a wave owns -> bf16 act in X16 layout (K' = N/2), S = 1
+// Algorithmic bytes per launch: 2*N*K.
+// ---------------------------------------------------------------------------
+template <int MT, int EPI, int RT>
+__global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X16, const bf16* __restrict__ W16, int M,
+                                                      int N, int K, int kslice, int wg_ksplit,
+                                                      float* __restrict__ slab, bf16* __restrict__ out, long ldo) {
+    extern __shared__ f32x4 red[];                          // wg_ksplit: [waves][RT][MT][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int rt0 = (wg_ksplit ? blockIdx.x : blockIdx.x * waves + wave) * RT;
+    const int n_tiles = N >> 4;
+    if (rt0 >= n_tiles) return;                             // whole workgroup when wg_ksplit; else no barrier below
+    const int nks = wg_ksplit ? (kslice >> 5) / waves : (kslice >> 5);
+    const int ks0 = blockIdx.y * (kslice >> 5) + (wg_ksplit ? wave * nks : 0);
+    const long tile_stride = (long)(K >> 5) * 512;
+    f32x4 acc[RT][MT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16* wp[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) wp[t] = W16 + (long)min(rt0 + t, n_tiles - 1) * tile_stride + (long)ks0 * 512 + lane * 8;
+    const bf16* xp = X16 + (long)ks0 * MT * 512 + lane * 8;
+    constexpr int G = RT == 1 ? 8 : 4;                      // ks steps per group
+    bf16x8 wA[G][RT], wB[G][RT];
+    auto loadw = [&](bf16x8 (&w)[G][RT], int ks) {
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+            if (ks + i < nks) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+                    w[i][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (long)(ks + i) * 512));
+            }
+    };
+    auto compute = [&](const bf16x8 (&w)[G][RT], int ks) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (ks + i < nks) {
+                bf16x8 xf[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(xp + ((long)(ks + i) * MT + mt) * 512);
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][t], xf[mt], acc[t][mt], 0, 0, 0);
+            }
+        }
+    };
+    loadw(wA, 0);
+    for (int ks = 0; ks < nks; ks += 2 * G) {
+        if (ks + G < nks) loadw(wB, ks + G);
+        compute(wA, ks);
+        if (ks + 2 * G < nks) loadw(wA, ks + 2 * G);
+        if (ks + G < nks) compute(wB, ks + G);
+    }
+    if (wg_ksplit) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) red[((wave * RT + t) * MT + mt) * 64 + lane] = acc[t][mt];
+        __syncthreads();
+        if (wave != 0) return;
+        for (int w = 1; w < waves; ++w)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[t][mt] += red[((w * RT + t) * MT + mt) * 64 + lane];
+    }
+    // lane (g, li) holds C[n = 16 (rt0+t) + 4 g + r][m = 16 mt + li]
+    const int g = lane >> 4, li = lane & 15;
+    if (EPI == 2) {
+#pragma unroll
+        for (int t = 0; t + 1 < RT; t += 2) {               // tile rt0+t = gate rows, rt0+t+1 = up rows of 16 features
+            const int f0 = ((rt0 + t) >> 1) * 16 + 4 * g;   // feature index = k of the down projection
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = 16 * mt + li;
+                if (m >= M) continue;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = round_bf(acc[t][mt][r]), b = round_bf(acc[t + 1 < RT ? t + 1 : t][mt][r]);   // bf16 gate/up (decoder.py:97)
+                    o[r] = f2bf(a / (1.0f + __expf(-a)) * b);
+                }
+                *reinterpret_cast<bf16x4*>(out + x16_index(m, f0, MT)) = o;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        if (rt0 + t >= n_tiles) break;
+        const int n = 16 * (rt0 + t) + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = 16 * mt + li;
+            if (m >= M) continue;
+            if (EPI == 0) {
+                *reinterpret_cast<f32x4*>(slab + ((long)blockIdx.y * M + m) * N + n) = acc[t][mt];
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[t][mt][r]);
+                *reinterpret_cast<bf16x4*>(out + (long)m * ldo + n) = o;
+            }
+        }
+    }
+}
+
+extern "C" int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, int N, int K, int n_splits, int epi,
+                                  int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out, int64_t ldo,
+                                  void* stream) {
+    Q3_REQUIRE(X16 && W16, "skinny3_gemm: null pointer");
+    Q3_REQUIRE(M > 0 && M <= 64 && N > 0 && N % 16 == 0, "skinny3_gemm: M=%d must be 1..64, N=%d a multiple of 16", M, N);
+    Q3_REQUIRE(epi >= 0 && epi <= 2 && (waves_per_wg == 1 || waves_per_wg == 2 || waves_per_wg == 4), "skinny3_gemm: bad epi/waves");
+    Q3_REQUIRE(tiles_per_wave == 1 || tiles_per_wave == 2 || tiles_per_wave == 4, "skinny3_gemm: tiles_per_wave=%d", tiles_per_wave);
+    Q3_REQUIRE(n_splits >= 1 && K % (n_splits * 32) == 0, "skinny3_gemm: K=%d must be a multiple of 32*n_splits (%d)", K, n_splits);
+    if (epi == 0) Q3_REQUIRE(slab, "skinny3_gemm: slab epilogue without workspace");
+    else Q3_REQUIRE(out && n_splits == 1, "skinny3_gemm: direct epilogues need out and n_splits == 1");
+    if (epi == 1) Q3_REQUIRE(ldo % 4 == 0 && ldo >= N, "skinny3_gemm: bad ldo");
+    if (epi == 2) Q3_REQUIRE(tiles_per_wave >= 2 && (N / 16) % tiles_per_wave == 0, "skinny3_gemm: SwiGLU needs whole (gate,up) tile pairs per wave");
+    const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int RT = tiles_per_wave;
+    const int n_tiles = N / 16;
+    const int per_wg = (wg_ksplit ? 1 : waves_per_wg) * RT;
+    if (wg_ksplit) Q3_REQUIRE((K / n_splits) % (32 * waves_per_wg) == 0, "skinny3_gemm: K slice not divisible among the waves");
+    dim3 grid((n_tiles + per_wg - 1) / per_wg, n_splits), blk(64 * waves_per_wg);
+    const size_t lds = wg_ksplit ? (size_t)waves_per_wg * RT * MT * 64 * sizeof(f32x4) : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bf16* x = (const bf16*)X16; const bf16* w = (const bf16*)W16; bf16* o = (bf16*)out;
+    const int kslice = K / n_splits;
+#define Q3_L(MT_, EPI_, RT_) hipLaunchKernelGGL((skinny3_kernel<MT_, EPI_, RT_>), grid, blk, lds, s, x, w, M, N, K, kslice, wg_ksplit, slab, o, (long)ldo)
+#define Q3_R(MT_, EPI_) do { if (RT == 1) Q3_L(MT_, EPI_, 1); else if (RT == 2) Q3_L(MT_, EPI_, 2); else Q3_L(MT_, EPI_, 4); } while (0)
+#define Q3_M(EPI_) do { if (MT == 1) Q3_R(1, EPI_); else if (MT == 2) Q3_R(2, EPI_); else Q3_R(4, EPI_); } while (0)
+    if (epi == 0) Q3_M(0); else if (epi == 1) Q3_M(1); else Q3_M(2);
+#undef Q3_M
+#undef Q3_R
+#undef Q3_L
+    return q3_check_launch("skinny3_gemm");
+}
+
+// ---------------------------------------------------------------------------
+// Slab consumer: h = bf16(h + bf16(sum_s slab_s)); x = RMSNorm(h) * w written in X16 layout
+// (decoder.py:191,194 / :196,189 / :251).  One workgroup per row; a thread owns 8 consecutive
+// columns = one X16 fragment (one 16-byte store).
+// ---------------------------------------------------------------------------
+template <int EPT>   // N = 256 * EPT, EPT in {2,4,8,16} (EPT < 8: N = 512/1024 handled with 8-wide threads, fewer active)
+__global__ __launch_bounds__(256) void slab_resnorm_x16_kernel(const float* __restrict__ slab, int S, long slab_stride,
+                                                               const bf16* __restrict__ h_in, bf16* __restrict__ h_out,
+                                                               const bf16* __restrict__ w, bf16* __restrict__ x16, int MT,
+                                                               float eps) {
+    __shared__ float red[4];
+    constexpr int N = 256 * EPT;
+    constexpr int NV = N / 8;                              // 8-wide vectors per row
+    const int m = blockIdx.x;
+    float q2 = 0.f;
+    float hv[(NV + 255) / 256][8];
+#pragma unroll
+    for (int it = 0; it < (NV + 255) / 256; ++it) {
+        const int v = threadIdx.x + 256 * it;
+        if (v < NV) {
+            const long c0 = (long)m * N + 8 * v;
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + c0), a1 = *reinterpret_cast<const f32x4*>(slab + c0 + 4);
+            int s = 1;
+            for (; s + 1 < S; s += 2) {                    // two slabs per trip: independent loads in flight
+                const float* p = slab + s * slab_stride + c0;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p), b1 = *reinterpret_cast<const f32x4*>(p + 4);
+                const f32x4 c0v = *reinterpret_cast<const f32x4*>(p + slab_stride), c1v = *reinterpret_cast<const f32x4*>(p + slab_stride + 4);
+                a0 += b0; a1 += b1; a0 += c0v; a1 += c1v;
+            }
+            if (s < S) {
+                const float* p = slab + s * slab_stride + c0;
+                a0 += *reinterpret_cast<const f32x4*>(p);
+                a1 += *reinterpret_cast<const f32x4*>(p + 4);
+            }
+            const bf16x8 hi = *reinterpret_cast<const bf16x8*>(h_in + c0);
+            bf16x8 ho;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = round_bf(round_bf(e < 4 ? a0[e] : a1[e - 4]) + bf2f(hi[e]));
+                hv[it][e] = t;
+                q2 = fmaf(t, t, q2);
+                ho[e] = f2bf(t);
+            }
+            *reinterpret_cast<bf16x8*>(h_out + c0) = ho;
+        }
+    }
+    q2 = wave_sum(q2);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q2;
+    __syncthreads();
+    const float r = rsqrtf((red[0] + red[1] + red[2] + red[3]) * (1.0f / N) + eps);
+#pragma unroll
+    for (int it = 0; it < (NV + 255) / 256; ++it) {
+        const int v = threadIdx.x + 256 * it;
+        if (v < NV) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + 8 * v);
+            bf16x8 xo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xo[e] = f2bf(hv[it][e] * r * bf2f(wv[e]));
+            *reinterpret_cast<bf16x8*>(x16 + x16_index(m, 8 * v, MT)) = xo;
+        }
+    }
+}
+
+extern "C" int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
+                                      const void* w, void* x16, int M, int N, float eps, void* stream) {
+    Q3_REQUIRE(slab && h_in && h_out && w && x16, "slab_resnorm_x16: null pointer");
+    Q3_REQUIRE(M > 0 && M <= 64 && n_slabs > 0 && (N == 512 || N == 1024 || N == 2048 || N == 4096), "slab_resnorm_x16: M=%d N=%d unsupported", M, N);
+    const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    dim3 grid(M), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bf16* hi = (const bf16*)h_in; bf16* ho = (bf16*)h_out; const bf16* ww = (const bf16*)w; bf16* xo = (bf16*)x16;
+    switch (N / 256) {
+        case 2: hipLaunchKernelGGL(slab_resnorm_x16_kernel<2>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps); break;
+        case 4: hipLaunchKernelGGL(slab_resnorm_x16_kernel<4>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps); break;
+        case 8: hipLaunchKernelGGL(slab_resnorm_x16_kernel<8>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps); break;
+        default: hipLaunchKernelGGL(slab_resnorm_x16_kernel<16>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps); break;
+    }
+    return q3_check_launch("slab_resnorm_x16");
+}
+
+// h = E[tok[m]] (or a given bf16 row when tok == nullptr); x16 = RMSNorm(h) * w   (generate.py:294 + decoder.py:189)
+template <int EPT>
+__global__ __launch_bounds__(256) void embed_norm_x16_kernel(const int* __restrict__ tok, const bf16* __restrict__ E,
+                                                             bf16* __restrict__ h_out, const bf16* __restrict__ w,
+                                                             bf16* __restrict__ x16, int MT, float eps) {
+    __shared__ float red[4];
+    constexpr int N = 256 * EPT;
+    constexpr int NV = N / 8;
+    const int m = blockIdx.x;
+    const bf16* src = E + (long)(tok ? tok[m] : m) * N;
+    float q2 = 0.f;
+    float hv[(NV + 255) / 256][8];
+#pragma unroll
+    for (int it = 0; it < (NV + 255) / 256; ++it) {
+        const int v = threadIdx.x + 256 * it;
+        if (v < NV) {
+            const bf16x8 hi = *reinterpret_cast<const bf16x8*>(src + 8 * v);
+            *reinterpret_cast<bf16x8*>(h_out + (long)m * N + 8 * v) = hi;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hv[it][e] = bf2f(hi[e]); q2 = fmaf(hv[it][e], hv[it][e], q2); }
+        }
+    }
+    q2 = wave_sum(q2);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q2;
+    __syncthreads();
+    const float r = rsqrtf((red[0] + red[1] + red[2] + red[3]) * (1.0f / N) + eps);
+#pragma unroll
+    for (int it = 0; it < (NV + 255) / 256; ++it) {
+        const int v = threadIdx.x + 256 * it;
+        if (v < NV) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + 8 * v);
+            bf16x8 xo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xo[e] = f2bf(hv[it][e] * r * bf2f(wv[e]));
+            *reinterpret_cast<bf16x8*>(x16 + x16_index(m, 8 * v, MT)) = xo;
+        }
+    }
+}
+
+extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_out, const void* w, void* x16, int M, int N,
+                                    float eps, void* stream) {
+    Q3_REQUIRE(E && h_out && w && x16, "embed_norm_x16: null pointer");
+    Q3_REQUIRE(M > 0 && M <= 64 && (N == 512 || N == 1024 || N == 2048 || N == 4096), "embed_norm_x16: M=%d N=%d unsupported", M, N);
+    const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    dim3 grid(M), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bf16* e = (const bf16*)E; bf16* ho = (bf16*)h_out; const bf16* ww = (const bf16*)w; bf16* xo = (bf16*)x16;
+    switch (N / 256) {
+        case 2: hipLaunchKernelGGL(embed_norm_x16_kernel<2>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps); break;
+        case 4: hipLaunchKernelGGL(embed_norm_x16_kernel<4>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps); break;
+        case 8: hipLaunchKernelGGL(embed_norm_x16_kernel<8>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps); break;
+        default: hipLaunchKernelGGL(embed_norm_x16_kernel<16>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps); break;
+    }
+    return q3_check_launch("embed_norm_x16");
+}
+
+// ---------------------------------------------------------------------------
+// Decode attention with the q/k RMSNorm + RoPE + KV append fused into its prologue
+// (decoder.py:140-163 at T = 1).  The qkv projection arrives as S fp32 split-K slabs [S][B][(nh+2nkv)*128];
+// their sum is rounded to bf16 (the projection's output dtype).  The attention output (the o
+// projection's operand) is written in X16 layout.
+// Workgroup (kv head, sequence): waves 0..3 normalise/rotate q0, q1, k and pass v through; the new
+// k/v go to the cache AND to LDS (the token attends to itself without a global round trip).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
+                                                                const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
+                                                                const float* __restrict__ inv_freq, float eps,
+                                                                bf16* __restrict__ k_cache, bf16* __restrict__ v_cache,
+                                                                const int* __restrict__ pos_arr, bf16* __restrict__ out16,
+                                                                int MT, int nh, int nkv, int Lmax, float scale) {
+    __shared__ float s_q[2][128];
+    __shared__ __attribute__((aligned(16))) bf16 s_k[128], s_v[128];
+    __shared__ float s_m[32][2], s_l[32][2];
+    __shared__ __attribute__((aligned(16))) float s_acc[32][2][128];
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int pos = pos_arr[b];
+    bf16* Kb = k_cache + ((long)b * nkv + kvh) * Lmax * 128;
+    bf16* Vb = v_cache + ((long)b * nkv + kvh) * Lmax * 128;
+    const int slot = wave * 4 + g;                                    // 32 token slots per 32-token sweep
+    bf16x8 kA[4], vA[4], kB[4], vB[4];
+    const int t_last = pos > 0 ? pos - 1 : 0;                         // tokens >= pos are never read from the cache
+#define Q3_LOAD_BATCH(KK, VV, T0)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
+        const int t_ = min((T0) + 32 * u + slot, t_last);                                           \
+        KK[u] = *reinterpret_cast<const bf16x8*>(Kb + (long)t_ * 128 + 8 * i);                      \
+        VV[u] = *reinterpret_cast<const bf16x8*>(Vb + (long)t_ * 128 + 8 * i);                      \
+    }
+    Q3_LOAD_BATCH(kA, vA, 0)
+    if (wave < 4) {
+        const int col = wave < 2 ? (2 * kvh + wave) * 128 : (wave == 2 ? (nh + kvh) * 128 : (nh + nkv + kvh) * 128);
+        const float* src = qkv + (long)b * ld + col;
+        float s1 = 0.f, s2 = 0.f;
+        for (int s = 0; s < n_slabs; ++s) { s1 += src[s * slab_stride + lane]; s2 += src[s * slab_stride + lane + 64]; }
+        const float x1 = round_bf(s1), x2 = round_bf(s2);
+        if (wave == 3) {
+            const bf16 v1 = f2bf(x1), v2 = f2bf(x2);
+            s_v[lane] = v1; s_v[lane + 64] = v2;
+            Vb[(long)pos * 128 + lane] = v1; Vb[(long)pos * 128 + lane + 64] = v2;
+        } else {
+            const bf16* nw = wave < 2 ? qn_w : kn_w;
+            const float ss = wave_sum(x1 * x1 + x2 * x2) * (1.0f / 128.0f);
+            const float r = rsqrtf(ss + eps);
+            const float y1 = round_bf(x1 * r * bf2f(nw[lane])), y2 = round_bf(x2 * r * bf2f(nw[lane + 64]));
+            float sn, cs;
+            sincosf((float)pos * inv_freq[lane], &sn, &cs);
+            const float o1 = round_bf(y1 * cs - y2 * sn), o2 = round_bf(y1 * sn + y2 * cs);
+            if (wave < 2) { s_q[wave][lane] = o1; s_q[wave][lane + 64] = o2; }
+            else {
+                s_k[lane] = f2bf(o1); s_k[lane + 64] = f2bf(o2);
+                Kb[(long)pos * 128 + lane] = f2bf(o1); Kb[(long)pos * 128 + lane + 64] = f2bf(o2);
+            }
+        }
+    }
+    // The first batch of cached keys/values does not depend on the prologue: it was issued above and is
+    // in flight across this barrier.
+    __syncthreads();
+    float q0[8], q1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { q0[e] = s_q[0][8 * i + e]; q1[e] = s_q[1][8 * i + e]; }
+    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#define Q3_COMPUTE(KK, VV, T0)                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
+        const int t = (T0) + 32 * u + slot;                                                         \
+        bf16x8 kf8 = KK[u], vf8 = VV[u];                                                            \
+        if (t == pos) { /* the new token: from LDS, not from HBM */                                 \
+            kf8 = *reinterpret_cast<const bf16x8*>(s_k + 8 * i);                                    \
+            vf8 = *reinterpret_cast<const bf16x8*>(s_v + 8 * i);                                    \
+        }                                                                                           \
+        float d0 = 0.f, d1 = 0.f;                                                                   \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                             \
+            const float kf = bf2f(kf8[e]);                                                          \
+            d0 = fmaf(q0[e], kf, d0);                                                               \
+            d1 = fmaf(q1[e], kf, d1);                                                               \
+        }                                                                                           \
+        _Pragma("unroll") for (int o = 1; o < 16; o <<= 1) {                                        \
+            d0 += __shfl_xor(d0, o, 64);                                                            \
+            d1 += __shfl_xor(d1, o, 64);                                                            \
+        }                                                                                           \
+        if (t <= pos) {                                                                             \
+            const float s0 = d0 * scale, s1 = d1 * scale;                                           \
+            const float n0 = fmaxf(m0, s0), n1 = fmaxf(m1, s1);                                     \
+            const float al0 = __expf(m0 - n0), al1 = __expf(m1 - n1);                               \
+            const float p0 = __expf(s0 - n0), p1 = __expf(s1 - n1);                                 \
+            l0 = l0 * al0 + p0;                                                                     \
+            l1 = l1 * al1 + p1;                                                                     \
+            m0 = n0;                                                                                \
+            m1 = n1;                                                                                \
+            const float pb0 = round_bf(p0), pb1 = round_bf(p1);                                     \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                         \
+                const float vf = bf2f(vf8[e]);                                                      \
+                a0[e] = fmaf(pb0, vf, a0[e] * al0);                                                 \
+                a1[e] = fmaf(pb1, vf, a1[e] * al1);                                                 \
+            }                                                                                       \
+        }                                                                                           \
+    }
+    const int L = pos + 1;
+    for (int t0 = 0; t0 < L; t0 += 256) {                              // register double buffer: 2 x 64 KiB per workgroup in flight
+        if (t0 + 128 < L) { Q3_LOAD_BATCH(kB, vB, t0 + 128) }
+        Q3_COMPUTE(kA, vA, t0)
+        if (t0 + 256 < L) { Q3_LOAD_BATCH(kA, vA, t0 + 256) }
+        if (t0 + 128 < L) { Q3_COMPUTE(kB, vB, t0 + 128) }
+    }
+#undef Q3_COMPUTE
+#undef Q3_LOAD_BATCH
+    if (i == 0) { s_m[slot][0] = m0; s_m[slot][1] = m1; s_l[slot][0] = l0; s_l[slot][1] = l1; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s_acc[slot][0][8 * i + e] = a0[e]; s_acc[slot][1][8 * i + e] = a1[e]; }
+    __syncthreads();
+    if (tid < 256) {
+        const int h = tid >> 7, d = tid & 127;
+        float Mx = -INFINITY;
+        for (int s = 0; s < 32; ++s) Mx = fmaxf(Mx, s_m[s][h]);
+        float num = 0.f, den = 0.f;
+        for (int s = 0; s < 32; ++s) {
+            const float w = __expf(s_m[s][h] - Mx);
+            num = fmaf(s_acc[s][h][d], w, num);
+            den = fmaf(s_l[s][h], w, den);
+        }
+        out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(num / den);
+    }
+}
+
+extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_slabs, int64_t slab_stride, const void* qn_w, const void* kn_w, const float* inv_freq,
+                                       float eps, void* k_cache, void* v_cache, const int32_t* pos, void* out, int B, int nh,
+                                       int nkv, int head_dim, int Lmax, float scale, void* stream) {
+    Q3_REQUIRE(qkv_slab && n_slabs > 0 && qn_w && kn_w && inv_freq && k_cache && v_cache && pos && out, "attn_decode_fused: null pointer");
+    Q3_REQUIRE(head_dim == 128 && nh == 2 * nkv, "attn_decode_fused: needs head_dim 128 and 2 query heads per kv head");
+    Q3_REQUIRE(B > 0 && B <= 64 && Lmax > 0 && ld >= (int64_t)(nh + 2 * nkv) * 128, "attn_decode_fused: bad sizes");
+    const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(nkv, B), dim3(512), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+                       (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
+                       nkv, Lmax, scale);
+    return q3_check_launch("attn_decode_fused");
+}

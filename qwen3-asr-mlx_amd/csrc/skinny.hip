@@ -130,36 +130,51 @@ extern "C" int q3asr_skinny_gemm(const void* X, int64_t ldx, int M, const void* 
 // ---------------------------------------------------------------------------
 
 // h_out = bf16(h_in + bf16(sum slabs)) ; x_out = RMSNorm(h_out) * w   (decoder.py:191,194 / :196,189 / :251)
-template <int EPT>   // elements per thread: N = 256 * EPT
+template <int EPT>   // elements per thread: N = 256 * EPT (EPT = 2: 8-byte accesses, else 16-byte)
 __global__ __launch_bounds__(256) void slab_residual_rmsnorm_kernel(const float* __restrict__ slab, int S, long slab_stride,
                                                                     const bf16* __restrict__ h_in, bf16* __restrict__ h_out,
                                                                     const bf16* __restrict__ w, bf16* __restrict__ x_out, float eps) {
     __shared__ float red[4];
     constexpr int N = 256 * EPT;
+    constexpr int VW = EPT >= 4 ? 4 : 2;                   // floats per vector load
+    typedef float fvec __attribute__((ext_vector_type(VW)));
+    typedef bf16 bvec __attribute__((ext_vector_type(VW)));
     const long m = blockIdx.x;
     const int c0 = threadIdx.x * EPT;
-    float v[EPT];
+    fvec v[EPT / VW];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) v[e] = 0.f;
-    for (int s = 0; s < S; ++s) {
+    for (int q = 0; q < EPT / VW; ++q) v[q] = *reinterpret_cast<const fvec*>(slab + m * N + c0 + q * VW);
+    for (int s = 1; s < S; ++s) {
         const float* p = slab + s * slab_stride + m * N + c0;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) v[e] += p[e];
+        for (int q = 0; q < EPT / VW; ++q) v[q] += *reinterpret_cast<const fvec*>(p + q * VW);
     }
-    float q = 0.f;
+    float q2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const float hv = round_bf(round_bf(v[e]) + bf2f(h_in[m * N + c0 + e]));
-        v[e] = hv;
-        q = fmaf(hv, hv, q);
-        h_out[m * N + c0 + e] = f2bf(hv);
+    for (int q = 0; q < EPT / VW; ++q) {
+        const bvec hv = *reinterpret_cast<const bvec*>(h_in + m * N + c0 + q * VW);
+        bvec ho;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const float t = round_bf(round_bf(v[q][e]) + bf2f(hv[e]));
+            v[q][e] = t;
+            q2 = fmaf(t, t, q2);
+            ho[e] = f2bf(t);
+        }
+        *reinterpret_cast<bvec*>(h_out + m * N + c0 + q * VW) = ho;
     }
-    q = wave_sum(q);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    q2 = wave_sum(q2);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q2;
     __syncthreads();
     const float r = rsqrtf((red[0] + red[1] + red[2] + red[3]) * (1.0f / N) + eps);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) x_out[m * N + c0 + e] = f2bf(v[e] * r * bf2f(w[c0 + e]));
+    for (int q = 0; q < EPT / VW; ++q) {
+        const bvec wv = *reinterpret_cast<const bvec*>(w + c0 + q * VW);
+        bvec xo;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) xo[e] = f2bf(v[q][e] * r * bf2f(wv[e]));
+        *reinterpret_cast<bvec*>(x_out + m * N + c0 + q * VW) = xo;
+    }
 }
 
 extern "C" int q3asr_slab_residual_rmsnorm(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,

@@ -82,11 +82,20 @@ class DecodeWorkspace:
         self.out_tokens = i32(B, max_out)
         self.h, self.x, self.q, self.att, self.act = bf(B, H), bf(B, H), bf(B, qd), bf(B, qd), bf(B, I)
         self.logits = bf(B, cfg.vocab_size)
+        self.cfg = cfg
+        self.MT = ops.mt_of(B)
+        rows = 16 * self.MT
+        self.x16, self.att16, self.act16 = bf(rows * H), bf(rows * qd), bf(rows * I)     # X16-layout operands
+        for t in (self.x16, self.att16, self.act16):
+            t.zero_()                                                                    # rows >= B stay zero
         self.splits = {
             "qkv": ops.pick_splits(qkvd, H), "o": ops.pick_splits(H, qd),
             "gu": ops.pick_splits(2 * I, H), "down": ops.pick_splits(H, I),
         }
-        n_slab = max(self.splits["qkv"] * qkvd, self.splits["o"] * H, self.splits["gu"] * 2 * I, self.splits["down"] * H)
+        self.geo = {"qkv": ops.gemm_geometry(qkvd, H), "o": ops.gemm_geometry(H, qd), "down": ops.gemm_geometry(H, I),
+                    "gu": ops.gemm_geometry(2 * I, H, swiglu=True), "head": ops.gemm_geometry(cfg.vocab_size, H, direct=True)}
+        n_slab = max(self.splits["qkv"] * qkvd, self.splits["o"] * H, self.splits["gu"] * 2 * I, self.splits["down"] * H,
+                     self.geo["qkv"][0] * qkvd, self.geo["o"][0] * H, self.geo["down"][0] * H)
         self.slab = torch.empty((n_slab * B,), dtype=torch.float32, device=device)
         self.graph = None
         self.graph_key = None
@@ -109,6 +118,7 @@ class TextDecoder:
         self.embed_tokens = None
         self._plans: dict = {}
         self._ws: dict = {}
+        self.decode_impl = "v3"      # "v1": row-major weights, X through LDS, separate rope/swiglu kernels (kept for A/B)
         self._caches: dict = {}
         self._api_ws = None
 
@@ -147,9 +157,13 @@ class TextDecoder:
                 "qn": bf(W[p + "self_attn.q_norm.weight"]), "kn": bf(W[p + "self_attn.k_norm.weight"]),
                 "wgu": bf(gu), "wdown": bf(W[p + "mlp.down_proj.weight"]),
             })
+            L = w["layers"][-1]
+            for name in ("wqkv", "wo", "wgu", "wdown"):            # decode-step copies in the streaming layout
+                L[name + "16"] = ops.to_w16(L[name])
         half = cfg.head_dim // 2
         # MLX nn.RoPE(traditional=False): angle = pos * base**(-i/half) (decoder.py:126)
         w["inv_freq"] = (float(cfg.rope_theta) ** (-torch.arange(half, dtype=torch.float32) / half)).to(dev)
+        w["embed16"] = ops.to_w16(w["embed"])
         self.w, self.device = w, dev
         self.embed_tokens = _Embedding(w["embed"])
 
@@ -262,6 +276,13 @@ class TextDecoder:
         eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
         sp = ws.splits
         layers = w["layers"]
+        if self.decode_impl == "v3":
+            ops.call("q3asr_embed_norm_x16", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
+                     ops.ptr(ws.x16), B, H, eps, ops.sp())
+            self._layers_decode_v3(ws, cache, ws.pos)
+            self._gemm3(ws, "head", ws.x16, w["embed16"], cfg.vocab_size, H, 1, out=ws.logits)
+            self.sample_step(ws, ws.logits, sampling)
+            return
         ops.call("q3asr_embed_rmsnorm", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
                  ops.ptr(ws.x), B, H, eps, ops.sp())
         for li, L in enumerate(layers):
@@ -282,6 +303,51 @@ class TextDecoder:
                      ops.ptr(nxt), ops.ptr(ws.x), B, H, eps, ops.sp())
         ops.skinny_gemm(ws.x, B, w["embed"], cfg.vocab_size, H, 1, None, ws.logits)
         self.sample_step(ws, ws.logits, sampling)
+
+    def _gemm3(self, ws: DecodeWorkspace, which: str, X16, W16, N, K, epi, out=None) -> int:
+        S, waves, rt, ksplit = ws.geo[which]
+        ops.skinny3(X16, ws.B, W16, N, K, epi, S, waves, slab=ws.slab if epi == 0 else None, out=out, rt=rt, ksplit=ksplit)
+        return S
+
+    def _layers_decode_v3(self, ws: DecodeWorkspace, cache: KVCache, pos) -> None:
+        """7 launches per layer, every GEMM operand in its streaming layout (W16 / X16):
+        qkv GEMM (slabs) -> attention with fused QK-norm / RoPE / KV append -> o GEMM (slabs) ->
+        residual + RMSNorm -> gate/up GEMM with SwiGLU epilogue -> down GEMM (slabs) -> residual + RMSNorm.
+        ws.x16 holds the normed input on entry and the final-norm output on exit."""
+        cfg, w = self.config, self.w
+        B, H, I = ws.B, cfg.hidden_size, cfg.intermediate_size
+        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
+        eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
+        layers = w["layers"]
+        for li, L in enumerate(layers):
+            s_qkv = self._gemm3(ws, "qkv", ws.x16, L["wqkv16"], qkvd, H, 0)
+            ops.call("q3asr_attn_decode_fused", ops.ptr(ws.slab), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),
+                     ops.ptr(w["inv_freq"]), eps, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(pos), ops.ptr(ws.att16),
+                     B, nh, nkv, hd, Lmax, scale, ops.sp())
+            s_o = self._gemm3(ws, "o", ws.att16, L["wo16"], H, qd, 0)
+            ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_o, B * H, ops.ptr(ws.h), ops.ptr(ws.h),
+                     ops.ptr(L["ln2"]), ops.ptr(ws.x16), B, H, eps, ops.sp())
+            self._gemm3(ws, "gu", ws.x16, L["wgu16"], 2 * I, H, 2, out=ws.act16)
+            s_d = self._gemm3(ws, "down", ws.act16, L["wdown16"], H, I, 0)
+            nxt = layers[li + 1]["ln1"] if li + 1 < len(layers) else w["norm"]
+            ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_d, B * H, ops.ptr(ws.h), ops.ptr(ws.h),
+                     ops.ptr(nxt), ops.ptr(ws.x16), B, H, eps, ops.sp())
+
+    def gemm_only_step(self, ws: DecodeWorkspace) -> int:
+        """bench.py roofline leg: exactly the weight-streaming GEMM launches of one decode step (4 per
+        layer + the tied head), same weights / operands / launch geometry, nothing else.  Returns the count."""
+        cfg, w = self.config, self.w
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        qd = cfg.num_attention_heads * cfg.head_dim
+        qkvd = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim
+        for L in w["layers"]:
+            self._gemm3(ws, "qkv", ws.x16, L["wqkv16"], qkvd, H, 0)
+            self._gemm3(ws, "o", ws.att16, L["wo16"], H, qd, 0)
+            self._gemm3(ws, "gu", ws.x16, L["wgu16"], 2 * I, H, 2, out=ws.act16)
+            self._gemm3(ws, "down", ws.act16, L["wdown16"], H, I, 0)
+        self._gemm3(ws, "head", ws.x16, w["embed16"], cfg.vocab_size, H, 1, out=ws.logits)
+        return 4 * len(w["layers"]) + 1
 
     def _skinny_slab(self, X, M, W, N, K, splits, slab):
         # always through the slab (splits may be 1): the consumer kernels read fp32 partials
@@ -362,9 +428,14 @@ class TextDecoder:
         qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
         eps, scale, Lmax, sp = cfg.rms_norm_eps, hd ** -0.5, cache.max_len, ws.splits
         ws.pos.fill_(off)
+        layers = w["layers"]
+        if self.decode_impl == "v3":
+            ops.call("q3asr_embed_norm_x16", None, ops.ptr(h), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]), ops.ptr(ws.x16), 1, H,
+                     eps, ops.sp())
+            self._layers_decode_v3(ws, cache, ws.pos)
+            return ops.from_x16(ws.x16, 1, ws.MT).contiguous()
         ws.h.copy_(h)
         ops.rmsnorm(ws.h, w["layers"][0]["ln1"], ws.x, 1, H, eps)
-        layers = w["layers"]
         for li, L in enumerate(layers):
             self._skinny_slab(ws.x, 1, L["wqkv"], qkvd, H, sp["qkv"], ws.slab)
             ops.call("q3asr_qk_norm_rope_kv", ops.ptr(ws.slab), 1, qkvd, sp["qkv"], qkvd, ops.ptr(ws.row_b), ops.ptr(ws.pos),

@@ -52,3 +52,72 @@ def pick_splits(N: int, K: int, target_wgs: int = 512) -> int:
         if tiles * s >= target_wgs:
             return s
     return valid[-1]
+
+
+# ---------------------------------------------------------------- decode-step streaming layouts
+def mt_of(M: int) -> int:
+    return 1 if M <= 16 else (2 if M <= 32 else 4)
+
+
+def to_w16(W):
+    """[N][K] -> W16 [N/16][K/32][64][8] (csrc/decode.hip); one-time re-tiling of static weights."""
+    N, K = W.shape
+    return W.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def to_x16(X, MT=None):
+    """[M][K] -> X16 [K/32][MT][64][8], rows padded with zeros (tests / API entry only)."""
+    import torch
+    M, K = X.shape
+    MT = MT or mt_of(M)
+    pad = torch.zeros((16 * MT, K), dtype=X.dtype, device=X.device)
+    pad[:M] = X
+    return pad.reshape(MT, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
+
+
+def from_x16(X16, M, MT=None):
+    """Inverse of to_x16 for any tensor holding K/32 * MT KiB-fragments (tests / API exit only)."""
+    MT = MT or mt_of(M)
+    v = X16.reshape(-1, MT, 4, 16, 8)
+    return v.permute(1, 3, 0, 2, 4).reshape(16 * MT, v.shape[0] * 32)[:M]
+
+
+def skinny3(X16, M, W16, N, K, epi, n_splits=1, waves=4, slab=None, out=None, ldo=None, rt=None, ksplit=False):
+    rt = rt if rt is not None else (2 if epi == 2 else 1)
+    call("q3asr_skinny3_gemm", ptr(X16), M, ptr(W16), N, K, n_splits, epi, waves, rt, 1 if ksplit else 0, ptr(slab), ptr(out),
+         ldo if ldo is not None else N, sp())
+
+
+def pick_splits3(N: int, K: int, waves: int = 4) -> int:
+    """Smallest split-K factor that gives >= 256 workgroups (one per CU), K slice >= 128."""
+    tiles = (N // 16 + waves - 1) // waves
+    valid = [s for s in (1, 2, 3, 4, 6, 8, 12, 16) if K % (32 * s) == 0 and K // s >= 128]
+    for s in valid:
+        if tiles * s >= 256:
+            return s
+    return valid[-1]
+
+
+# Launch geometry of the decode-step GEMMs, measured on MI355X with tools/bench_skinny*.py under rocprofv3
+# (cold weights, batch 32; profiles/r01_skinny_sweep.md).  (N, K) -> (n_splits, waves, tiles/wave, wg_ksplit)
+_TUNED = {
+    (4096, 2048): (8, 2, 1, False),      # qkv      6.6 us
+    (2048, 2048): (8, 2, 1, False),      # o        5.0 us
+    (2048, 6144): (6, 4, 2, True),       # down     7.9 us
+    (12288, 2048): (1, 4, 2, True),      # gate/up  13.0 us (SwiGLU epilogue, complete sums per workgroup)
+    (151936, 2048): (1, 2, 2, False),    # tied head 117 us (5.3 TB/s)
+}
+
+
+def gemm_geometry(N: int, K: int, swiglu: bool = False, direct: bool = False):
+    """(n_splits, waves, tiles_per_wave, wg_ksplit) for skinny3 on an (N, K) weight."""
+    g = _TUNED.get((N, K))
+    if g is not None and (g[0] == 1 or not (swiglu or direct)):
+        return g
+    if swiglu:                                        # complete sums needed: waves split K inside the workgroup
+        for waves in (4, 2, 1):
+            if K % (32 * waves) == 0 and (N // 16) % 2 == 0:
+                return (1, waves, 2, waves > 1)
+    if direct:
+        return (1, 4, 1, False)
+    return (pick_splits3(N, K, 2), 2, 1, False)

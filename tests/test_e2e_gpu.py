@@ -249,3 +249,19 @@ def test_full_size_batch_invariance_30s(dev, full):
     for i in (0, 3):
         assert model.generate_tokens([xs[i]], [10], "English")[0] == batched[i]
     assert model.generate_tokens(xs[::-1], [10] * 4, "English") == batched[::-1]
+
+
+def test_decode_v1_and_v3_agree(dev, small):
+    """The two decode-step implementations share rounding points: same tokens."""
+    cfg, state, model = small
+    x = signal("speechlike", 80000, seed=9)
+    v3 = model.generate_tokens([x], [20], "English")[0]
+    model._decoder.decode_impl = "v1"
+    model._decoder._ws.clear()
+    try:
+        v1 = model.generate_tokens([x], [20], "English")[0]
+    finally:
+        model._decoder.decode_impl = "v3"
+        model._decoder._ws.clear()
+    agree = sum(a == b for a, b in zip(v1, v3))
+    assert v1[0] == v3[0] and agree >= 16

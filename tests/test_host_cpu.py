@@ -153,6 +153,15 @@ def test_decode_split_choice():
     for n, k in ((2048, 2048), (1024, 512), (2048, 1024)):
         s = ops.pick_splits(n, k)
         assert k % (s * 256) == 0
+    assert ops.gemm_geometry(4096, 2048) == (8, 2, 1, False) and ops.gemm_geometry(12288, 2048, swiglu=True) == (1, 4, 2, True)
+    for n, k in ((1024, 512), (512, 1024), (2048, 512)):             # small-config shapes: generic rule
+        S, waves, rt, ks = ops.gemm_geometry(n, k)
+        assert k % (32 * S) == 0 and (not ks or (k // S) % (32 * waves) == 0)
+    S, waves, rt, ks = ops.gemm_geometry(2048, 512, swiglu=True)
+    assert S == 1 and rt == 2 and 512 % (32 * waves) == 0
+    for n, k in ((1024, 512), (512, 1024), (151936, 2048)):
+        s = ops.pick_splits3(n, k)
+        assert k % (32 * s) == 0 and k // s >= 128
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

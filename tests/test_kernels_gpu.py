@@ -432,3 +432,120 @@ def test_slab_consumers_and_embed_rmsnorm(dev):
     ops.call("q3asr_embed_rmsnorm", ops.ptr(tok), ops.ptr(E), ops.ptr(ho), ops.ptr(w), ops.ptr(xo), M, N, 1e-6, ops.sp())
     assert torch.equal(ho, E[tok.long()])
     torch.testing.assert_close(xo.float().cpu(), od.rms_norm(E[tok.long()].float().cpu(), w.float().cpu(), 1e-6), atol=0, rtol=8e-3)
+
+
+
+# ----------------------------------------------------------------------------- decode step in streaming layouts (W16 / X16)
+def test_w16_x16_layout_roundtrip(dev):
+    from qwen3_asr_mlx_amd import ops
+    X = rnd((21, 256), dev, 129)
+    assert torch.equal(ops.from_x16(ops.to_x16(X), 21), X)
+    W = torch.arange(32 * 64, dtype=torch.float32).reshape(32, 64).to(torch.bfloat16).to(dev)
+    w16 = ops.to_w16(W)
+    assert w16.shape == (2, 2, 4, 16, 8)
+    rt, ks, g, li, j = 1, 1, 2, 5, 3
+    assert w16[rt, ks, g, li, j] == W[16 * rt + li, 32 * ks + 8 * g + j]
+
+
+@pytest.mark.parametrize("M,N,K,S,waves", [(1, 1024, 512, 4, 4), (7, 4096, 2048, 4, 4), (32, 2048, 6144, 8, 4),
+                                           (32, 2048, 2048, 8, 4), (33, 512, 1024, 1, 2), (64, 2048, 2048, 2, 4),
+                                           (16, 48, 256, 1, 4), (20, 2048, 6144, 3, 1)])
+def test_skinny3_slab_and_rowmajor(dev, M, N, K, S, waves):
+    from qwen3_asr_mlx_amd import ops
+    X = rnd((M, K), dev, 130)
+    W = rnd((N, K), dev, 131, 1.0 / math.sqrt(K))
+    x16, w16 = ops.to_x16(X), ops.to_w16(W)
+    ref = X.float().cpu() @ W.float().cpu().T
+    for rt in (1, 2, 4):
+        slab = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.skinny3(x16, M, w16, N, K, 0, S, waves, slab=slab, rt=rt)
+        torch.testing.assert_close(slab.sum(0).cpu(), ref, atol=2e-3, rtol=1e-3)
+        if S == 1:
+            out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            ops.skinny3(x16, M, w16, N, K, 1, 1, waves, out=out, rt=rt)
+            torch.testing.assert_close(out.float().cpu(), bfr(ref), atol=2e-2, rtol=8e-3)
+        if (K // S) % (32 * waves) == 0:                      # waves of a workgroup split K, LDS reduce
+            slab = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+            ops.skinny3(x16, M, w16, N, K, 0, S, waves, slab=slab, rt=rt, ksplit=True)
+            torch.testing.assert_close(slab.sum(0).cpu(), ref, atol=2e-3, rtol=1e-3)
+
+
+def test_skinny3_identity_layout(dev):
+    from qwen3_asr_mlx_amd import ops
+    K = 1024
+    X = torch.eye(K, dtype=torch.bfloat16, device=dev)[300:348].contiguous()
+    W = (torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 241 - 120).to(torch.bfloat16).to(dev)
+    out = torch.empty((48, 192), dtype=torch.bfloat16, device=dev)
+    ops.skinny3(ops.to_x16(X), 48, ops.to_w16(W), 192, K, 1, out=out)
+    assert torch.equal(out.float().cpu(), W.float().cpu()[:, 300:348].T)
+
+
+@pytest.mark.parametrize("M,I,K,waves", [(32, 6144, 2048, 2), (5, 1024, 512, 4), (64, 256, 256, 2)])
+def test_skinny3_swiglu_to_x16(dev, M, I, K, waves):
+    from qwen3_asr_mlx_amd import ops
+    A = rnd((M, K), dev, 132)
+    gate = rnd((I, K), dev, 133, 2.0 / math.sqrt(K))
+    up = rnd((I, K), dev, 134, 2.0 / math.sqrt(K))
+    gu = torch.stack([gate.reshape(I // 16, 16, K), up.reshape(I // 16, 16, K)], 1).reshape(2 * I, K).contiguous()
+    MT = ops.mt_of(M)
+    g, u = bfr(A.float().cpu() @ gate.float().cpu().T), bfr(A.float().cpu() @ up.float().cpu().T)
+    for rt, ksplit in ((2, False), (4, False), (2, True), (4, True)):
+        o16 = torch.zeros((I // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.skinny3(ops.to_x16(A), M, ops.to_w16(gu), 2 * I, K, 2, 1, waves, out=o16, rt=rt, ksplit=ksplit)
+        got = ops.from_x16(o16, M).float().cpu()
+        torch.testing.assert_close(got, bfr(g * torch.sigmoid(g) * u), atol=2e-2, rtol=1.6e-2)
+
+
+@pytest.mark.parametrize("M,N,S", [(5, 2048, 3), (32, 2048, 8), (33, 512, 1), (2, 4096, 2)])
+def test_slab_resnorm_and_embed_norm_x16(dev, M, N, S):
+    import oracle.decoder as od
+    from qwen3_asr_mlx_amd import ops
+    slab = rnd((S, M, N), dev, 120, 0.5, torch.float32)
+    h = rnd((M, N), dev, 121)
+    w = rnd((N,), dev, 122) + 1
+    MT = ops.mt_of(M)
+    ho = torch.empty_like(h)
+    x16 = torch.zeros((N // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_slab_resnorm_x16", ops.ptr(slab), S, M * N, ops.ptr(h), ops.ptr(ho), ops.ptr(w), ops.ptr(x16), M, N, 1e-6, ops.sp())
+    tot = slab[0].clone()
+    for s in range(1, S):
+        tot += slab[s]
+    href = bfr(bfr(tot.cpu()) + h.float().cpu())
+    torch.testing.assert_close(ho.float().cpu(), href, atol=0, rtol=8e-3)        # summation order of S slabs: <= 1 ulp
+    xr = od.rms_norm(ho.float().cpu(), w.float().cpu(), 1e-6)
+    torch.testing.assert_close(ops.from_x16(x16, M).float().cpu(), xr, atol=0, rtol=8e-3)
+    E = rnd((50, N), dev, 124)
+    tok = torch.randint(0, 50, (M,), dtype=torch.int32).to(dev)
+    ops.call("q3asr_embed_norm_x16", ops.ptr(tok), ops.ptr(E), ops.ptr(ho), ops.ptr(w), ops.ptr(x16), M, N, 1e-6, ops.sp())
+    assert torch.equal(ho, E[tok.long()])
+    torch.testing.assert_close(ops.from_x16(x16, M).float().cpu(), od.rms_norm(E[tok.long()].float().cpu(), w.float().cpu(), 1e-6),
+                               atol=0, rtol=8e-3)
+
+
+@pytest.mark.parametrize("B,poss,S", [(1, [0], 1), (3, [5, 127, 200], 4), (2, [408, 535], 2)])
+def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S):
+    """Fused prologue (slab input, X16 output) == q3asr_qk_norm_rope_kv followed by q3asr_attn_decode."""
+    from qwen3_asr_mlx_amd import ops
+    nh, nkv, hd, Lmax = 4, 2, 128, 576
+    qkvd = (nh + 2 * nkv) * hd
+    parts = rnd((S, B, qkvd), dev, 140, 1.0, torch.float32)
+    qn, kn = rnd((hd,), dev, 141) + 1, rnd((hd,), dev, 142) + 1
+    inv = (1e6 ** (-torch.arange(64, dtype=torch.float32) / 64)).to(dev)
+    kc0, vc0 = rnd((B, nkv, Lmax, hd), dev, 143), rnd((B, nkv, Lmax, hd), dev, 144)
+    pos = torch.tensor(poss, dtype=torch.int32, device=dev)
+    rb = torch.arange(B, dtype=torch.int32, device=dev)
+    kc1, vc1 = kc0.clone(), vc0.clone()
+    q = torch.zeros((B, nh * hd), dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_qk_norm_rope_kv", ops.ptr(parts), 1, qkvd, S, B * qkvd, ops.ptr(rb), ops.ptr(pos), ops.ptr(qn), ops.ptr(kn),
+             ops.ptr(inv), 1e-6, ops.ptr(q), ops.ptr(kc1), ops.ptr(vc1), B, nh, nkv, hd, Lmax, ops.sp())
+    ref = torch.zeros((B, nh * hd), dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_attn_decode", ops.ptr(q), ops.ptr(kc1), ops.ptr(vc1), ops.ptr(pos), ops.ptr(ref), B, nh, nkv, hd, Lmax,
+             hd ** -0.5, ops.sp())
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    MT = ops.mt_of(B)
+    o16 = torch.zeros((nh * hd // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
+             ops.ptr(kc2), ops.ptr(vc2), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.sp())
+    assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+    # same maths; the partial-merge grouping differs (4 tokens per group per sweep instead of 2)
+    torch.testing.assert_close(ops.from_x16(o16, B).float(), ref.float(), atol=1e-2, rtol=8e-3)
