@@ -343,7 +343,17 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
         const int col = wave < 2 ? (2 * kvh + wave) * 128 : (wave == 2 ? (nh + kvh) * 128 : (nh + nkv + kvh) * 128);
         const float* src = qkv + (long)b * ld + col;
         float s1 = 0.f, s2 = 0.f;
-        for (int s = 0; s < n_slabs; ++s) { s1 += src[s * slab_stride + lane]; s2 += src[s * slab_stride + lane + 64]; }
+        for (int s0 = 0; s0 < n_slabs; s0 += 8) {            // 8 slabs per trip: 16 independent loads in flight
+            float p1[8], p2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = s0 + u < n_slabs;
+                p1[u] = in ? src[(s0 + u) * slab_stride + lane] : 0.f;
+                p2[u] = in ? src[(s0 + u) * slab_stride + lane + 64] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += p1[u]; s2 += p2[u]; }      // fixed order s = 0, 1, ...
+        }
         const float x1 = round_bf(s1), x2 = round_bf(s2);
         if (wave == 3) {
             const bf16 v1 = f2bf(x1), v2 = f2bf(x2);

@@ -141,12 +141,30 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_step_kernel(const SamplePa
     // ---- pass 1: max value, lowest index (this IS greedy)
     float best = -INFINITY;
     int best_i = 0x7fffffff;
-    for (int c = tid; c < nchunks; c += SMP_THREADS) {
-        float v[8];
-        load8(row, c, bitmap, sh, sampling, t_bf, v);
+    for (int c0 = tid; c0 < nchunks; c0 += 4 * SMP_THREADS) {            // 4 x 16-byte loads in flight per thread
+        bf16x8 raw[4];
+        unsigned bits[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (v[e] > best) { best = v[e]; best_i = 8 * c + e; }
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + u * SMP_THREADS, nchunks - 1);
+            raw[u] = *reinterpret_cast<const bf16x8*>(row + 8 * c);
+            bits[u] = bitmap[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * SMP_THREADS;
+            if (c >= nchunks) break;
+            float v[8];
+            if (bits[u] || sampling) {
+                load8(row, c, bitmap, sh, sampling, t_bf, v);             // rare: penalised id in this chunk, or temperature path
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = bf2f(raw[u][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (v[e] > best) { best = v[e]; best_i = 8 * c + e; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
