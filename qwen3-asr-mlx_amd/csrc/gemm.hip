@@ -36,6 +36,66 @@ struct GemmParams {
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
+// Epilogue shared by both GEMM kernels.  A lane holds, for accumulator tile (j, i): output row
+// m = m_base + 16 i + li and the 4 consecutive columns n = n_base + 16 j + 4 g + r.
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, int n0, int wn,
+                                              int g, int li) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m_base + i * 16 + li;
+        if (m >= p.M) continue;
+        long orow = m;
+        if (p.row_map) {
+            orow = p.row_map[m];
+            if (orow < 0) continue;
+        }
+        const long rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+        if (p.act == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int n_in = n_base + j * 16 + 4 * g;            // gate rows; up rows are n_in + 16
+                if (n_in >= p.N) continue;
+                const int n_out = (n0 >> 1) + wn * 32 + (j >> 1) * 16 + 4 * g;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gt = round_bf(acc[j][i][r]);            // gate_proj output is bf16 (decoder.py:97)
+                    const float up = round_bf(acc[j + 1][i][r]);
+                    o[r] = f2bf(gt / (1.0f + __expf(-gt)) * up);
+                }
+                *reinterpret_cast<bf16x4*>((bf16*)p.out + orow * p.ldo + n_out) = o;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n_base + j * 16 + 4 * g;
+            if (n >= p.N) continue;
+            f32x4 v = acc[j][i];
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (p.res_kind == 1) {
+                v += *reinterpret_cast<const f32x4*>((const float*)p.res + rrow * p.ldres + n);
+            } else if (p.res_kind == 2) {
+                const bf16x4 rv = *reinterpret_cast<const bf16x4*>((const bf16*)p.res + rrow * p.ldres + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = round_bf(v[r]) + bf2f(rv[r]);
+            }
+            if (p.out_kind == 1) {
+                *reinterpret_cast<f32x4*>((float*)p.out + orow * p.ldo + n) = v;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+                *reinterpret_cast<bf16x4*>((bf16*)p.out + orow * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
 template <int CONV>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * BM * BK * 2];   // A0 | W0 | A1 | W1, 16 KB each
@@ -150,64 +210,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds, for tile (j,i): row m = .. + li, columns n = .. + 4g + r, r = 0..3
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + li;
-        if (m >= p.M) continue;
-        long orow = m;
-        if (p.row_map) {
-            orow = p.row_map[m];
-            if (orow < 0) continue;
-        }
-        const long rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
-        if (p.act == 2) {
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const int n_in = n0 + wn * 64 + j * 16 + 4 * g;      // gate rows; up rows are n_in + 16
-                if (n_in >= p.N) continue;
-                const int n_out = (n0 >> 1) + wn * 32 + (j >> 1) * 16 + 4 * g;
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gt = round_bf(acc[j][i][r]);            // gate_proj output is bf16 (decoder.py:97)
-                    const float up = round_bf(acc[j + 1][i][r]);
-                    o[r] = f2bf(gt / (1.0f + __expf(-gt)) * up);
-                }
-                *reinterpret_cast<bf16x4*>((bf16*)p.out + orow * p.ldo + n_out) = o;
-            }
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * g;
-            if (n >= p.N) continue;
-            f32x4 v = acc[j][i];
-            if (p.bias) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-                v += bv;
-            }
-            if (p.act == 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (p.res_kind == 1) {
-                v += *reinterpret_cast<const f32x4*>((const float*)p.res + rrow * p.ldres + n);
-            } else if (p.res_kind == 2) {
-                const bf16x4 rv = *reinterpret_cast<const bf16x4*>((const bf16*)p.res + rrow * p.ldres + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = round_bf(v[r]) + bf2f(rv[r]);
-            }
-            if (p.out_kind == 1) {
-                *reinterpret_cast<f32x4*>((float*)p.out + orow * p.ldo + n) = v;
-            } else {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-                *reinterpret_cast<bf16x4*>((bf16*)p.out + orow * p.ldo + n) = o;
-            }
-        }
-    }
+    gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, n0, wn, g, li);
+}
+
+static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
+    const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
+    if (conv) hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(tiles), dim3(256), 0, s, p);
 }
 
 static int gemm_validate(const GemmParams& p, const char* who) {
@@ -238,8 +247,7 @@ extern "C" int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
     p.out = out; p.out_kind = out_kind; p.ldo = ldo; p.row_map = row_map;
     if (int rc = gemm_validate(p, "gemm_bf16")) return rc;
     Q3_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_bf16: lda=%ld must be >= K and a multiple of 8", (long)lda);
-    const unsigned tiles = (unsigned)((M + BM - 1) / BM) * (unsigned)((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+    gemm_launch(p, false, (hipStream_t)stream);
     return q3_check_launch("gemm_bf16");
 }
 
@@ -259,7 +267,6 @@ extern "C" int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, i
     Q3_REQUIRE((long)imgs * p.Hout * p.Wout < 2147483647L, "conv3x3s2: M overflows int32");
     if (int rc = gemm_validate(p, "conv3x3s2")) return rc;
     Q3_REQUIRE(act != 2, "conv3x3s2: SwiGLU epilogue not valid here");
-    const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+    gemm_launch(p, true, (hipStream_t)stream);
     return q3_check_launch("conv3x3s2");
 }
