@@ -19,10 +19,10 @@ __global__ __launch_bounds__(256) void conv1_gelu_kernel(const float* __restrict
                                                          const int* __restrict__ chunk_b, const int* __restrict__ chunk_f0,
                                                          const float* __restrict__ w9 /*[C1][kt][kf]*/,
                                                          const float* __restrict__ bias, bf16* __restrict__ out, int C1) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* in_s = sm;                    // [3][130]  (f = -1 .. 128)
-    float* w_s = sm + 3 * 130;           // [9][C1]
-    float* b_s = w_s + 9 * C1;           // [C1]
+    // One workgroup per (chunk, output time step): 64 output frequencies x C1 channels.  A thread owns one
+    // channel octet for the whole row: its 72 weights and 8 biases live in registers, the 3 input rows in
+    // LDS are read as broadcasts (all lanes of a wave work on the same frequency at a time).
+    __shared__ float in_s[3 * 130];      // [kt][f + 1], f = -1 .. 128
     const int ci = blockIdx.y, ot = blockIdx.x;
     const int TOUT = (C1_TIN - 1) / 2 + 1, FOUT = (C1_FIN - 1) / 2 + 1;
     const int b = chunk_b[ci], f0 = chunk_f0[ci];
@@ -35,16 +35,22 @@ __global__ __launch_bounds__(256) void conv1_gelu_kernel(const float* __restrict
             v = mel[((long)b * C1_FIN + f) * Fmax + f0 + t];
         in_s[i] = v;
     }
-    for (int i = tid; i < 9 * C1; i += 256) {
-        const int co = i / 9, tap = i - co * 9;
-        w_s[tap * C1 + co] = w9[i];
-    }
-    for (int i = tid; i < C1; i += 256) b_s[i] = bias[i];
-    __syncthreads();
     const int octs = C1 / 8;
-    bf16* obase = out + ((long)(ci * TOUT + ot) * FOUT) * C1;
-    for (int item = tid; item < FOUT * octs; item += 256) {
-        const int of = item / octs, c8 = (item - of * octs) * 8;
+    const int groups = 256 / octs;                          // frequency lanes processed concurrently (4 for C1 = 480)
+    const int oc = tid % octs, fg = tid / octs;
+    float w[8][9], bb[8];
+    if (fg < groups) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bb[e] = bias[oc * 8 + e];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) w[e][tap] = w9[(oc * 8 + e) * 9 + tap];
+        }
+    }
+    __syncthreads();
+    if (fg >= groups) return;
+    bf16* obase = out + ((long)(ci * TOUT + ot) * FOUT) * C1 + oc * 8;
+    for (int of = fg; of < FOUT; of += groups) {
         float x[9];
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt)
@@ -53,21 +59,20 @@ __global__ __launch_bounds__(256) void conv1_gelu_kernel(const float* __restrict
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float a = b_s[c8 + e];
+            float a = bb[e];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) a = fmaf(w_s[tap * C1 + c8 + e], x[tap], a);
+            for (int tap = 0; tap < 9; ++tap) a = fmaf(w[e][tap], x[tap], a);
             o[e] = f2bf(gelu_erf(a));
         }
-        *reinterpret_cast<bf16x8*>(obase + (long)of * C1 + c8) = o;
+        *reinterpret_cast<bf16x8*>(obase + (long)of * C1) = o;
     }
 }
 
 extern "C" int q3asr_conv1_gelu(const float* mel, int Fmax, const int32_t* chunk_b, const int32_t* chunk_f0, int n_chunks,
                                 const float* w9, const float* bias, void* out, int C1, void* stream) {
     Q3_REQUIRE(mel && chunk_b && chunk_f0 && w9 && bias && out, "conv1_gelu: null pointer");
-    Q3_REQUIRE(n_chunks > 0 && Fmax > 0 && C1 > 0 && C1 % 8 == 0 && C1 <= 1024, "conv1_gelu: bad sizes (n_chunks=%d C1=%d)", n_chunks, C1);
-    const size_t lds = sizeof(float) * (3 * 130 + 10 * C1);
-    hipLaunchKernelGGL(conv1_gelu_kernel, dim3(50, n_chunks), dim3(256), lds, (hipStream_t)stream, mel, Fmax, chunk_b,
+    Q3_REQUIRE(n_chunks > 0 && Fmax > 0 && C1 > 0 && C1 % 8 == 0 && C1 <= 2048, "conv1_gelu: bad sizes (n_chunks=%d C1=%d, C1 <= 2048)", n_chunks, C1);
+    hipLaunchKernelGGL(conv1_gelu_kernel, dim3(50, n_chunks), dim3(256), 0, (hipStream_t)stream, mel, Fmax, chunk_b,
                        chunk_f0, w9, bias, (bf16*)out, C1);
     return q3_check_launch("conv1_gelu");
 }
