@@ -44,14 +44,15 @@ def synth_clip(i: int, n: int) -> np.ndarray:
     return signal("speechlike", n, seed=1234 + i)
 
 
-def decode_bytes_per_launch(cfg, B: int):
+def decode_bytes_per_launch(cfg, B: int, bytes_per_weight: int = 2):
     """Algorithmic bytes of one skinny-GEMM launch = weight bytes (2*N*K); list over one decode step."""
     t = cfg.text_decoder
     H, I = t.hidden_size, t.intermediate_size
     qd = t.num_attention_heads * t.head_dim
     qkvd = (t.num_attention_heads + 2 * t.num_key_value_heads) * t.head_dim
-    per_layer = [2 * qkvd * H, 2 * H * qd, 2 * 2 * I * H, 2 * H * I]
-    return per_layer * t.num_hidden_layers + [2 * t.vocab_size * H]
+    w = bytes_per_weight
+    per_layer = [w * qkvd * H, w * H * qd, w * 2 * I * H, w * H * I]
+    return per_layer * t.num_hidden_layers + [w * t.vocab_size * H]
 
 
 def cpu_baseline(cfg, state, clip, n_dec_sample: int, n_dec_full: int):
@@ -109,6 +110,8 @@ def main() -> None:
     ap.add_argument("--ndec", type=int, default=128, help="decoded tokens per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--weights", choices=("bf16", "fp8"), default="bf16",
+                    help="fp8: decoder weights quantised on load (BASELINE.json configs[4]; not the headline config)")
     args = ap.parse_args()
 
     import torch
@@ -138,7 +141,7 @@ def main() -> None:
     cfg = ModelConfig()                                     # Qwen3-ASR-1.7B defaults (reference config.py)
     log("building synthetic 1.7B weights on the device")
     state = synth.random_state(cfg, seed=0, device=dev)
-    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype=args.weights)
     log("model ready")
     model.use_graph = not args.no_graph
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
@@ -220,7 +223,7 @@ def main() -> None:
         "metric": "real-time factor (audio-sec/wall-sec), Qwen3-ASR-1.7B bf16 30s clips",
         "value": audio_s / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "bf16" if args.weights == "bf16" else "bf16 activations, fp8-e4m3 decoder weights", "data": "synthetic",
         "config": {"workload": f"Qwen3-ASR-1.7B bf16, batch={B}/GPU, {args.clip_seconds:g} s clips, greedy (repetition_penalty 1.2), "
                                f"{args.ndec} decoded tokens/clip, hipGraph decode" + ("" if world == 1 else f", {world}-GPU DP over RCCL"),
                    "batch_per_gpu": B, "clip_seconds": args.clip_seconds, "decoded_tokens": args.ndec,
@@ -262,7 +265,7 @@ def main() -> None:
             launches += dec.gemm_only_step(ws)
         _lib.check(lib.q3asr_event_record(e1, stream), "event_record")
         _lib.check(lib.q3asr_event_elapsed_ms(e0, e1, C.byref(ms)), "event_elapsed")
-        per_launch = decode_bytes_per_launch(cfg, B)
+        per_launch = decode_bytes_per_launch(cfg, B, 2 if args.weights == "bf16" else 1)
         total_bytes = sum(per_launch) * R
         avg_ms = ms.value / launches
         achieved = total_bytes / (ms.value * 1e-3) / 1e9
@@ -276,7 +279,7 @@ def main() -> None:
                             "kernel": "skinny3_kernel (decode weight streaming, all shapes of one step)",
                             "launches_measured": launches, "avg_launch_us": 1e3 * avg_ms,
                             "bytes_per_launch": sum(per_launch) / len(per_launch)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.weights == "bf16":
             model.close()
             torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline(cfg, state, synth_clip(0, n), 8, args.ndec)

@@ -103,10 +103,12 @@ int q3asr_slab_swiglu(const float* slab, int n_slabs, int64_t slab_stride, void*
  * skinny3: one wave per 16-row weight tile and K slice, global -> MFMA, no LDS.
  *   epi 0: fp32 slabs [n_splits][M][N]; epi 1: bf16 row-major out [M][ldo]; epi 2: SwiGLU of
  *   (gate tile, up tile) pairs -> bf16 X16 (K' = N/2).  waves_per_wg, tiles_per_wave in {1,2,4};
- *   wg_ksplit != 0: the waves of a workgroup split its K slice and reduce through LDS (fixed order). */
-int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, int N, int K, int n_splits, int epi,
-                       int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out, int64_t ldo,
-                       void* stream);
+ *   wg_ksplit != 0: the waves of a workgroup split its K slice and reduce through LDS (fixed order).
+ *   w_scale != NULL: W16 is fp8 e4m3 in W16F8 layout [N/16][K/64][64][16 B] with one fp32 scale per row
+ *   (BASELINE.json configs[4]); NULL: bf16 W16. */
+int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, const float* w_scale, int N, int K, int n_splits,
+                       int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out,
+                       int64_t ldo, void* stream);
 /* h = bf16(h + bf16(sum slabs)); x16 = RMSNorm(h)*w in X16 layout (decoder.py:191-196,189,251) */
 int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
                            const void* w, void* x16, int M, int N, float eps, void* stream);

@@ -28,9 +28,22 @@ __device__ __forceinline__ long x16_index(int m, int k, int MT) {      // elemen
 //   EPI 2: SwiGLU of the (gate tile, up tile) pairs a wave owns -> bf16 act in X16 layout (K' = N/2), S = 1
 // Algorithmic bytes per launch: 2*N*K.
 // ---------------------------------------------------------------------------
-template <int MT, int EPI, int RT>
-__global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X16, const bf16* __restrict__ W16, int M,
-                                                      int N, int K, int kslice, int wg_ksplit,
+// fp8 (OCP e4m3) weights: W16F8 [N/16][K/64][64 lanes][16 B] -- a lane's 16 bytes are its fragments of two
+// consecutive 32-wide k steps (bytes 0-7: step 2q, bytes 8-15: step 2q+1) -- plus one fp32 scale per weight
+// row.  The bytes are widened to bf16 in registers (exact) and go through the same bf16 MFMA; the row scale
+// multiplies the accumulator in the epilogue.  Half the HBM bytes of the bf16 stream.
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(unsigned lo, unsigned hi) {
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    bf16x8 r;
+    r[0] = f2bf(a[0]); r[1] = f2bf(a[1]); r[2] = f2bf(b[0]); r[3] = f2bf(b[1]);
+    r[4] = f2bf(c[0]); r[5] = f2bf(c[1]); r[6] = f2bf(d[0]); r[7] = f2bf(d[1]);
+    return r;
+}
+
+template <int MT, int EPI, int RT, bool F8>
+__global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X16, const void* __restrict__ Wt, int M,
+                                                      int N, int K, int kslice, int wg_ksplit, const float* __restrict__ w_scale,
                                                       float* __restrict__ slab, bf16* __restrict__ out, long ldo) {
     extern __shared__ f32x4 red[];                          // wg_ksplit: [waves][RT][MT][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -40,48 +53,98 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
     if (rt0 >= n_tiles) return;                             // whole workgroup when wg_ksplit; else no barrier below
     const int nks = wg_ksplit ? (kslice >> 5) / waves : (kslice >> 5);
     const int ks0 = blockIdx.y * (kslice >> 5) + (wg_ksplit ? wave * nks : 0);
-    const long tile_stride = (long)(K >> 5) * 512;
     f32x4 acc[RT][MT];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16* wp[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) wp[t] = W16 + (long)min(rt0 + t, n_tiles - 1) * tile_stride + (long)ks0 * 512 + lane * 8;
     const bf16* xp = X16 + (long)ks0 * MT * 512 + lane * 8;
-    constexpr int G = RT == 1 ? 8 : 4;                      // ks steps per group
-    bf16x8 wA[G][RT], wB[G][RT];
-    auto loadw = [&](bf16x8 (&w)[G][RT], int ks) {
+    if (!F8) {
+        const bf16* W16 = (const bf16*)Wt;
+        const long tile_stride = (long)(K >> 5) * 512;
+        const bf16* wp[RT];
 #pragma unroll
-        for (int i = 0; i < G; ++i)
-            if (ks + i < nks) {
+        for (int t = 0; t < RT; ++t) wp[t] = W16 + (long)min(rt0 + t, n_tiles - 1) * tile_stride + (long)ks0 * 512 + lane * 8;
+        constexpr int G = RT == 1 ? 8 : 4;                  // ks steps per group
+        bf16x8 wA[G][RT], wB[G][RT];
+        auto loadw = [&](bf16x8 (&w)[G][RT], int ks) {
 #pragma unroll
-                for (int t = 0; t < RT; ++t)
-                    w[i][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (long)(ks + i) * 512));
+            for (int i = 0; i < G; ++i)
+                if (ks + i < nks) {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+                        w[i][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp[t] + (long)(ks + i) * 512));
+                }
+        };
+        auto compute = [&](const bf16x8 (&w)[G][RT], int ks) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                if (ks + i < nks) {
+                    bf16x8 xf[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(xp + ((long)(ks + i) * MT + mt) * 512);
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][t], xf[mt], acc[t][mt], 0, 0, 0);
+                }
             }
-    };
-    auto compute = [&](const bf16x8 (&w)[G][RT], int ks) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            if (ks + i < nks) {
-                bf16x8 xf[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(xp + ((long)(ks + i) * MT + mt) * 512);
-#pragma unroll
-                for (int t = 0; t < RT; ++t)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][t], xf[mt], acc[t][mt], 0, 0, 0);
-            }
+        };
+        loadw(wA, 0);
+        for (int ks = 0; ks < nks; ks += 2 * G) {
+            if (ks + G < nks) loadw(wB, ks + G);
+            compute(wA, ks);
+            if (ks + 2 * G < nks) loadw(wA, ks + 2 * G);
+            if (ks + G < nks) compute(wB, ks + G);
         }
-    };
-    loadw(wA, 0);
-    for (int ks = 0; ks < nks; ks += 2 * G) {
-        if (ks + G < nks) loadw(wB, ks + G);
-        compute(wA, ks);
-        if (ks + 2 * G < nks) loadw(wA, ks + 2 * G);
-        if (ks + G < nks) compute(wB, ks + G);
+    } else {
+        const char* W8 = (const char*)Wt;
+        const long tile_stride = (long)(K >> 6) * 1024;     // bytes per 16-row tile
+        const int nkp = nks >> 1, kp0 = ks0 >> 1;           // pairs of k steps
+        const char* wp[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) wp[t] = W8 + (long)min(rt0 + t, n_tiles - 1) * tile_stride + (long)kp0 * 1024 + lane * 16;
+        constexpr int G = RT == 1 ? 8 : 4;                  // pairs per group: the same bytes in flight as the bf16 path
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 wA[G][RT], wB[G][RT];
+        auto loadw = [&](u32x4 (&w)[G][RT], int kp) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (kp + i < nkp) {
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+                        w[i][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + (long)(kp + i) * 1024));
+                }
+        };
+        auto compute = [&](const u32x4 (&w)[G][RT], int kp) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                if (kp + i < nkp) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        bf16x8 xf[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            xf[mt] = *reinterpret_cast<const bf16x8*>(xp + ((long)(2 * (kp + i) + h) * MT + mt) * 512);
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) {
+                            const bf16x8 wf = h == 0 ? fp8x8_to_bf16(w[i][t][0], w[i][t][1]) : fp8x8_to_bf16(w[i][t][2], w[i][t][3]);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mt], acc[t][mt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        };
+        loadw(wA, 0);
+        for (int kp = 0; kp < nkp; kp += 2 * G) {
+            if (kp + G < nkp) loadw(wB, kp + G);
+            compute(wA, kp);
+            if (kp + 2 * G < nkp) loadw(wA, kp + 2 * G);
+            if (kp + G < nkp) compute(wB, kp + G);
+        }
     }
     if (wg_ksplit) {
 #pragma unroll
@@ -98,6 +161,14 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
     }
     // lane (g, li) holds C[n = 16 (rt0+t) + 4 g + r][m = 16 mt + li]
     const int g = lane >> 4, li = lane & 15;
+    if (F8) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(w_scale + 16 * min(rt0 + t, n_tiles - 1) + 4 * g);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[t][mt] *= sc;
+        }
+    }
     if (EPI == 2) {
 #pragma unroll
         for (int t = 0; t + 1 < RT; t += 2) {               // tile rt0+t = gate rows, rt0+t+1 = up rows of 16 features
@@ -137,14 +208,15 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
     }
 }
 
-extern "C" int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, int N, int K, int n_splits, int epi,
-                                  int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out, int64_t ldo,
-                                  void* stream) {
+extern "C" int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, const float* w_scale, int N, int K, int n_splits,
+                                  int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out,
+                                  int64_t ldo, void* stream) {
     Q3_REQUIRE(X16 && W16, "skinny3_gemm: null pointer");
     Q3_REQUIRE(M > 0 && M <= 64 && N > 0 && N % 16 == 0, "skinny3_gemm: M=%d must be 1..64, N=%d a multiple of 16", M, N);
     Q3_REQUIRE(epi >= 0 && epi <= 2 && (waves_per_wg == 1 || waves_per_wg == 2 || waves_per_wg == 4), "skinny3_gemm: bad epi/waves");
     Q3_REQUIRE(tiles_per_wave == 1 || tiles_per_wave == 2 || tiles_per_wave == 4, "skinny3_gemm: tiles_per_wave=%d", tiles_per_wave);
-    Q3_REQUIRE(n_splits >= 1 && K % (n_splits * 32) == 0, "skinny3_gemm: K=%d must be a multiple of 32*n_splits (%d)", K, n_splits);
+    const int kq = w_scale ? 64 : 32;                       // fp8 tiles are addressed in pairs of k steps
+    Q3_REQUIRE(n_splits >= 1 && K % (n_splits * kq) == 0, "skinny3_gemm: K=%d must be a multiple of %d*n_splits (%d)", K, kq, n_splits);
     if (epi == 0) Q3_REQUIRE(slab, "skinny3_gemm: slab epilogue without workspace");
     else Q3_REQUIRE(out && n_splits == 1, "skinny3_gemm: direct epilogues need out and n_splits == 1");
     if (epi == 1) Q3_REQUIRE(ldo % 4 == 0 && ldo >= N, "skinny3_gemm: bad ldo");
@@ -153,18 +225,20 @@ extern "C" int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, int N
     const int RT = tiles_per_wave;
     const int n_tiles = N / 16;
     const int per_wg = (wg_ksplit ? 1 : waves_per_wg) * RT;
-    if (wg_ksplit) Q3_REQUIRE((K / n_splits) % (32 * waves_per_wg) == 0, "skinny3_gemm: K slice not divisible among the waves");
+    if (wg_ksplit) Q3_REQUIRE((K / n_splits) % (kq * waves_per_wg) == 0, "skinny3_gemm: K slice not divisible among the waves");
     dim3 grid((n_tiles + per_wg - 1) / per_wg, n_splits), blk(64 * waves_per_wg);
     const size_t lds = wg_ksplit ? (size_t)waves_per_wg * RT * MT * 64 * sizeof(f32x4) : 0;
     hipStream_t s = (hipStream_t)stream;
-    const bf16* x = (const bf16*)X16; const bf16* w = (const bf16*)W16; bf16* o = (bf16*)out;
+    const bf16* x = (const bf16*)X16; bf16* o = (bf16*)out;
     const int kslice = K / n_splits;
-#define Q3_L(MT_, EPI_, RT_) hipLaunchKernelGGL((skinny3_kernel<MT_, EPI_, RT_>), grid, blk, lds, s, x, w, M, N, K, kslice, wg_ksplit, slab, o, (long)ldo)
-#define Q3_R(MT_, EPI_) do { if (RT == 1) Q3_L(MT_, EPI_, 1); else if (RT == 2) Q3_L(MT_, EPI_, 2); else Q3_L(MT_, EPI_, 4); } while (0)
+#define Q3_L(MT_, EPI_, RT_, F8_) hipLaunchKernelGGL((skinny3_kernel<MT_, EPI_, RT_, F8_>), grid, blk, lds, s, x, W16, M, N, K, kslice, wg_ksplit, w_scale, slab, o, (long)ldo)
+#define Q3_F(MT_, EPI_, RT_) do { if (w_scale) Q3_L(MT_, EPI_, RT_, true); else Q3_L(MT_, EPI_, RT_, false); } while (0)
+#define Q3_R(MT_, EPI_) do { if (RT == 1) Q3_F(MT_, EPI_, 1); else if (RT == 2) Q3_F(MT_, EPI_, 2); else Q3_F(MT_, EPI_, 4); } while (0)
 #define Q3_M(EPI_) do { if (MT == 1) Q3_R(1, EPI_); else if (MT == 2) Q3_R(2, EPI_); else Q3_R(4, EPI_); } while (0)
     if (epi == 0) Q3_M(0); else if (epi == 1) Q3_M(1); else Q3_M(2);
 #undef Q3_M
 #undef Q3_R
+#undef Q3_F
 #undef Q3_L
     return q3_check_launch("skinny3_gemm");
 }

@@ -123,9 +123,15 @@ class TextDecoder:
         self._api_ws = None
 
     # ------------------------------------------------------------------ weights
-    def load_state(self, W: dict, device) -> None:
+    def load_state(self, W: dict, device, weight_dtype: str = "bf16") -> None:
         """W: checkpoint tensors with the ``model.`` prefix stripped (reference decoder.py:282-290).
-        Strict key set.  The lm_head is tied to embed_tokens (decoder.py:252)."""
+        Strict key set.  The lm_head is tied to embed_tokens (decoder.py:252).
+        weight_dtype "fp8" (BASELINE.json configs[4]): projection and embedding weights are quantised on
+        load to OCP e4m3 with a power-of-two scale per output row; prefill uses the exactly-equal bf16
+        values, the decode step streams the fp8 bytes (half the HBM traffic)."""
+        if weight_dtype not in ("bf16", "fp8"):
+            raise ValueError(f"weight_dtype must be 'bf16' or 'fp8', got {weight_dtype!r}")
+        self.weight_dtype = weight_dtype
         import torch
         cfg = self.config
         dev = torch.device(device)
@@ -144,26 +150,33 @@ class TextDecoder:
             return t.to(device=dev, dtype=torch.bfloat16).contiguous()
 
         I = cfg.intermediate_size
-        w = {"embed": bf(W["embed_tokens.weight"]), "norm": bf(W["norm.weight"]), "layers": []}
+        fp8 = weight_dtype == "fp8"
+
+        def stream_form(dst: dict, name: str, mat):
+            """dst[name] = row-major bf16 (prefill / gather), dst[name+'16'] = decode streaming layout."""
+            if fp8:
+                q8, scale, w_eff = ops.quantize_fp8_rows(mat)
+                dst[name], dst[name + "16"], dst[name + "_s"] = w_eff.contiguous(), ops.to_w16f8(q8), scale
+            else:
+                dst[name], dst[name + "16"], dst[name + "_s"] = mat, ops.to_w16(mat), None
+
+        w = {"norm": bf(W["norm.weight"]), "layers": []}
+        stream_form(w, "embed", bf(W["embed_tokens.weight"]))
         for i in range(cfg.num_hidden_layers):
             p = f"layers.{i}."
             gate, up = W[p + "mlp.gate_proj.weight"].to(dev), W[p + "mlp.up_proj.weight"].to(dev)
             gu = torch.stack([gate.reshape(I // 16, 16, -1), up.reshape(I // 16, 16, -1)], dim=1).reshape(2 * I, -1)
-            w["layers"].append({
-                "ln1": bf(W[p + "input_layernorm.weight"]), "ln2": bf(W[p + "post_attention_layernorm.weight"]),
-                "wqkv": bf(torch.cat([W[p + "self_attn.q_proj.weight"], W[p + "self_attn.k_proj.weight"],
-                                      W[p + "self_attn.v_proj.weight"]], 0)),
-                "wo": bf(W[p + "self_attn.o_proj.weight"]),
-                "qn": bf(W[p + "self_attn.q_norm.weight"]), "kn": bf(W[p + "self_attn.k_norm.weight"]),
-                "wgu": bf(gu), "wdown": bf(W[p + "mlp.down_proj.weight"]),
-            })
-            L = w["layers"][-1]
-            for name in ("wqkv", "wo", "wgu", "wdown"):            # decode-step copies in the streaming layout
-                L[name + "16"] = ops.to_w16(L[name])
+            L = {"ln1": bf(W[p + "input_layernorm.weight"]), "ln2": bf(W[p + "post_attention_layernorm.weight"]),
+                 "qn": bf(W[p + "self_attn.q_norm.weight"]), "kn": bf(W[p + "self_attn.k_norm.weight"])}
+            stream_form(L, "wqkv", bf(torch.cat([W[p + "self_attn.q_proj.weight"], W[p + "self_attn.k_proj.weight"],
+                                                 W[p + "self_attn.v_proj.weight"]], 0)))
+            stream_form(L, "wo", bf(W[p + "self_attn.o_proj.weight"]))
+            stream_form(L, "wgu", bf(gu))
+            stream_form(L, "wdown", bf(W[p + "mlp.down_proj.weight"]))
+            w["layers"].append(L)
         half = cfg.head_dim // 2
         # MLX nn.RoPE(traditional=False): angle = pos * base**(-i/half) (decoder.py:126)
         w["inv_freq"] = (float(cfg.rope_theta) ** (-torch.arange(half, dtype=torch.float32) / half)).to(dev)
-        w["embed16"] = ops.to_w16(w["embed"])
         self.w, self.device = w, dev
         self.embed_tokens = _Embedding(w["embed"])
 
@@ -280,7 +293,7 @@ class TextDecoder:
             ops.call("q3asr_embed_norm_x16", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
                      ops.ptr(ws.x16), B, H, eps, ops.sp())
             self._layers_decode_v3(ws, cache, ws.pos)
-            self._gemm3(ws, "head", ws.x16, w["embed16"], cfg.vocab_size, H, 1, out=ws.logits)
+            self._gemm3(ws, "head", ws.x16, w, "embed", cfg.vocab_size, H, 1, out=ws.logits)
             self.sample_step(ws, ws.logits, sampling)
             return
         ops.call("q3asr_embed_rmsnorm", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
@@ -304,9 +317,10 @@ class TextDecoder:
         ops.skinny_gemm(ws.x, B, w["embed"], cfg.vocab_size, H, 1, None, ws.logits)
         self.sample_step(ws, ws.logits, sampling)
 
-    def _gemm3(self, ws: DecodeWorkspace, which: str, X16, W16, N, K, epi, out=None) -> int:
+    def _gemm3(self, ws: DecodeWorkspace, which: str, X16, holder: dict, name: str, N, K, epi, out=None) -> int:
         S, waves, rt, ksplit = ws.geo[which]
-        ops.skinny3(X16, ws.B, W16, N, K, epi, S, waves, slab=ws.slab if epi == 0 else None, out=out, rt=rt, ksplit=ksplit)
+        ops.skinny3(X16, ws.B, holder[name + "16"], N, K, epi, S, waves, slab=ws.slab if epi == 0 else None, out=out, rt=rt,
+                    ksplit=ksplit, scale=holder[name + "_s"])
         return S
 
     def _layers_decode_v3(self, ws: DecodeWorkspace, cache: KVCache, pos) -> None:
@@ -321,15 +335,15 @@ class TextDecoder:
         eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
         layers = w["layers"]
         for li, L in enumerate(layers):
-            s_qkv = self._gemm3(ws, "qkv", ws.x16, L["wqkv16"], qkvd, H, 0)
+            s_qkv = self._gemm3(ws, "qkv", ws.x16, L, "wqkv", qkvd, H, 0)
             ops.call("q3asr_attn_decode_fused", ops.ptr(ws.slab), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),
                      ops.ptr(w["inv_freq"]), eps, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(pos), ops.ptr(ws.att16),
                      B, nh, nkv, hd, Lmax, scale, ops.sp())
-            s_o = self._gemm3(ws, "o", ws.att16, L["wo16"], H, qd, 0)
+            s_o = self._gemm3(ws, "o", ws.att16, L, "wo", H, qd, 0)
             ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_o, B * H, ops.ptr(ws.h), ops.ptr(ws.h),
                      ops.ptr(L["ln2"]), ops.ptr(ws.x16), B, H, eps, ops.sp())
-            self._gemm3(ws, "gu", ws.x16, L["wgu16"], 2 * I, H, 2, out=ws.act16)
-            s_d = self._gemm3(ws, "down", ws.act16, L["wdown16"], H, I, 0)
+            self._gemm3(ws, "gu", ws.x16, L, "wgu", 2 * I, H, 2, out=ws.act16)
+            s_d = self._gemm3(ws, "down", ws.act16, L, "wdown", H, I, 0)
             nxt = layers[li + 1]["ln1"] if li + 1 < len(layers) else w["norm"]
             ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_d, B * H, ops.ptr(ws.h), ops.ptr(ws.h),
                      ops.ptr(nxt), ops.ptr(ws.x16), B, H, eps, ops.sp())
@@ -342,11 +356,11 @@ class TextDecoder:
         qd = cfg.num_attention_heads * cfg.head_dim
         qkvd = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim
         for L in w["layers"]:
-            self._gemm3(ws, "qkv", ws.x16, L["wqkv16"], qkvd, H, 0)
-            self._gemm3(ws, "o", ws.att16, L["wo16"], H, qd, 0)
-            self._gemm3(ws, "gu", ws.x16, L["wgu16"], 2 * I, H, 2, out=ws.act16)
-            self._gemm3(ws, "down", ws.act16, L["wdown16"], H, I, 0)
-        self._gemm3(ws, "head", ws.x16, w["embed16"], cfg.vocab_size, H, 1, out=ws.logits)
+            self._gemm3(ws, "qkv", ws.x16, L, "wqkv", qkvd, H, 0)
+            self._gemm3(ws, "o", ws.att16, L, "wo", H, qd, 0)
+            self._gemm3(ws, "gu", ws.x16, L, "wgu", 2 * I, H, 2, out=ws.act16)
+            self._gemm3(ws, "down", ws.act16, L, "wdown", H, I, 0)
+        self._gemm3(ws, "head", ws.x16, w, "embed", cfg.vocab_size, H, 1, out=ws.logits)
         return 4 * len(w["layers"]) + 1
 
     def _skinny_slab(self, X, M, W, N, K, splits, slab):
@@ -455,9 +469,10 @@ class TextDecoder:
         return ws.x.clone()
 
 
-def load_decoder_weights(decoder: TextDecoder, model_path: str | Path, device: Optional[str] = None) -> None:
+def load_decoder_weights(decoder: TextDecoder, model_path: str | Path, device: Optional[str] = None,
+                         weight_dtype: str = "bf16") -> None:
     """Load ``model.*`` from model.safetensors (reference decoder.py:260-291)."""
     import torch
     from .encoder import _read_safetensors
     dev = device or f"cuda:{torch.cuda.current_device()}"
-    decoder.load_state(_read_safetensors(model_path, "model."), dev)
+    decoder.load_state(_read_safetensors(model_path, "model."), dev, weight_dtype)

@@ -79,6 +79,7 @@ class Qwen3ASR:
         """Local model directory (config.json, model.safetensors, tokenizer files) or a Hub repo id
         (downloaded with snapshot_download(**kwargs); needs network).  Extra keyword ``device``."""
         device = kwargs.pop("device", None)
+        weight_dtype = kwargs.pop("weight_dtype", "bf16")          # "fp8": BASELINE.json configs[4]
         path = Path(model_id_or_path)
         if not path.is_dir():
             from huggingface_hub import snapshot_download
@@ -87,18 +88,18 @@ class Qwen3ASR:
         encoder = AudioEncoder(config.audio_encoder)
         load_encoder_weights(encoder, path, device)
         decoder = TextDecoder(config.text_decoder)
-        load_decoder_weights(decoder, path, device)
+        load_decoder_weights(decoder, path, device, weight_dtype)
         return cls(config, encoder, decoder, Tokenizer(path))
 
     @classmethod
-    def from_state_dict(cls, config: ModelConfig, state: dict, tokenizer, device=None) -> "Qwen3ASR":
+    def from_state_dict(cls, config: ModelConfig, state: dict, tokenizer, device=None, weight_dtype: str = "bf16") -> "Qwen3ASR":
         """Build from in-memory checkpoint tensors (keys as in model.safetensors)."""
         import torch
         dev = device or f"cuda:{torch.cuda.current_device()}"
         encoder = AudioEncoder(config.audio_encoder)
         encoder.load_state({k[len("audio_tower."):]: v for k, v in state.items() if k.startswith("audio_tower.")}, dev)
         decoder = TextDecoder(config.text_decoder)
-        decoder.load_state({k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}, dev)
+        decoder.load_state({k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}, dev, weight_dtype)
         return cls(config, encoder, decoder, tokenizer)
 
     # ------------------------------------------------------------------ public API

@@ -82,9 +82,10 @@ def from_x16(X16, M, MT=None):
     return v.permute(1, 3, 0, 2, 4).reshape(16 * MT, v.shape[0] * 32)[:M]
 
 
-def skinny3(X16, M, W16, N, K, epi, n_splits=1, waves=4, slab=None, out=None, ldo=None, rt=None, ksplit=False):
+def skinny3(X16, M, W16, N, K, epi, n_splits=1, waves=4, slab=None, out=None, ldo=None, rt=None, ksplit=False, scale=None):
+    """W16: bf16 W16 tensor, or (with `scale` fp32 [N]) fp8 bytes in W16F8 layout."""
     rt = rt if rt is not None else (2 if epi == 2 else 1)
-    call("q3asr_skinny3_gemm", ptr(X16), M, ptr(W16), N, K, n_splits, epi, waves, rt, 1 if ksplit else 0, ptr(slab), ptr(out),
+    call("q3asr_skinny3_gemm", ptr(X16), M, ptr(W16), ptr(scale), N, K, n_splits, epi, waves, rt, 1 if ksplit else 0, ptr(slab), ptr(out),
          ldo if ldo is not None else N, sp())
 
 
@@ -121,3 +122,23 @@ def gemm_geometry(N: int, K: int, swiglu: bool = False, direct: bool = False):
     if direct:
         return (1, 4, 1, False)
     return (pick_splits3(N, K, 2), 2, 1, False)
+
+
+# ---------------------------------------------------------------- fp8 weights (BASELINE.json configs[4])
+def quantize_fp8_rows(W):
+    """Per-output-row power-of-two scale + OCP e4m3 values.  Returns (q8 uint8 [N][K], scale fp32 [N],
+    W_eff bf16 [N][K]) with W_eff = scale * fp8 EXACTLY representable in bf16, so the prefill GEMM (bf16
+    W_eff) and the decode GEMM (fp8 + scale) use identical effective weights."""
+    import torch
+    Wf = W.float()
+    amax = Wf.abs().amax(dim=1).clamp_min(1e-30)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
+    q = (Wf / scale[:, None]).to(torch.float8_e4m3fn)
+    w_eff = (q.float() * scale[:, None]).to(torch.bfloat16)
+    return q.view(torch.uint8), scale.contiguous(), w_eff
+
+
+def to_w16f8(q8):
+    """uint8 [N][K] -> W16F8 [N/16][K/64][64 lanes][16 B] (lane = 16 g + li; byte = 8 half + j)."""
+    N, K = q8.shape
+    return q8.reshape(N // 16, 16, K // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).contiguous()

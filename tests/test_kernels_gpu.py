@@ -549,3 +549,49 @@ def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S):
     assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
     # same maths; the partial-merge grouping differs (4 tokens per group per sweep instead of 2)
     torch.testing.assert_close(ops.from_x16(o16, B).float(), ref.float(), atol=1e-2, rtol=8e-3)
+
+
+# ----------------------------------------------------------------------------- fp8 weights (BASELINE.json configs[4])
+def test_fp8_row_quantisation_is_exact_in_bf16(dev):
+    from qwen3_asr_mlx_amd import ops
+    W = rnd((64, 256), dev, 150, 0.05)
+    q8, scale, w_eff = ops.quantize_fp8_rows(W)
+    assert q8.dtype == torch.uint8 and scale.shape == (64,)
+    assert torch.equal(torch.exp2(torch.round(torch.log2(scale))), scale)                  # powers of two
+    back = q8.view(torch.float8_e4m3fn).float() * scale[:, None]
+    assert torch.equal(back, w_eff.float())                                                 # scale * fp8 is exact in bf16
+    assert (w_eff.float() - W.float()).abs().max() <= 0.07 * W.float().abs().max()          # e4m3: 3 mantissa bits
+    t = ops.to_w16f8(q8)
+    rt, kq, g, li, half, j = 2, 3, 1, 7, 1, 5
+    assert t[rt, kq, g, li, half, j] == q8[16 * rt + li, 64 * kq + 32 * half + 8 * g + j]
+
+
+@pytest.mark.parametrize("M,N,K,S,waves,rt,ksplit,epi", [(32, 4096, 2048, 8, 2, 1, False, 0), (7, 2048, 6144, 6, 4, 2, True, 0),
+                                                         (32, 12288, 2048, 1, 4, 2, True, 2), (33, 1024, 512, 1, 2, 2, False, 1),
+                                                         (1, 2048, 2048, 4, 4, 1, False, 0)])
+def test_skinny3_fp8_weights(dev, M, N, K, S, waves, rt, ksplit, epi):
+    from qwen3_asr_mlx_amd import ops
+    X = rnd((M, K), dev, 151)
+    W = rnd((N, K), dev, 152, 1.5 / math.sqrt(K))
+    q8, scale, w_eff = ops.quantize_fp8_rows(W)
+    x16, w8 = ops.to_x16(X), ops.to_w16f8(q8)
+    ref = X.float().cpu() @ w_eff.float().cpu().T
+    if epi == 0:
+        slab = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.skinny3(x16, M, w8, N, K, 0, S, waves, slab=slab, rt=rt, ksplit=ksplit, scale=scale)
+        torch.testing.assert_close(slab.sum(0).cpu(), ref, atol=2e-3, rtol=1e-3)
+        # identical effective weights: the bf16 path on W_eff gives the same numbers up to summation order
+        slab2 = torch.empty_like(slab)
+        ops.skinny3(x16, M, ops.to_w16(w_eff), N, K, 0, S, waves, slab=slab2, rt=rt, ksplit=ksplit)
+        torch.testing.assert_close(slab.sum(0), slab2.sum(0), atol=1e-4, rtol=1e-4)
+    elif epi == 1:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        ops.skinny3(x16, M, w8, N, K, 1, 1, waves, out=out, rt=rt, scale=scale)
+        torch.testing.assert_close(out.float().cpu(), bfr(ref), atol=2e-2, rtol=8e-3)
+    else:
+        I = N // 2
+        o16 = torch.zeros((I // 32, ops.mt_of(M), 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.skinny3(x16, M, w8, N, K, 2, 1, waves, out=o16, rt=rt, ksplit=ksplit, scale=scale)
+        r = ref.reshape(M, I // 16, 2, 16)
+        g, u = bfr(r[:, :, 0].reshape(M, I)), bfr(r[:, :, 1].reshape(M, I))
+        torch.testing.assert_close(ops.from_x16(o16, M).float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=2e-2, rtol=1.6e-2)
