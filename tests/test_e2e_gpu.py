@@ -312,3 +312,61 @@ def test_config5_longform_fp8_sampling(dev):
     assert r.duration == 150.0 and r.language == "English" and isinstance(r.text, str)
     # exactly 20 min with the default chunk_duration is NOT chunked (strict >, model.py:313)
     assert not (1200.0 > 1200.0)
+
+
+# ----------------------------------------------------------------------------- reference API objects (tests/test_decoder.py, test_audio.py)
+def test_kv_cache_and_mask_api(dev, small):
+    """KVCache growth as seen through the reference's attributes (test_decoder.py:254-283) and the
+    additive causal mask helper (decoder.py:71-80)."""
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd.decoder import create_additive_causal_mask
+    cfg, state, model = small
+    t = cfg.text_decoder
+    cache = q.KVCache()
+    assert cache.offset == 0 and cache.keys == [] and cache.values == []
+    ids = torch.tensor([[5, 17, 300, 42]])
+    logits = model._decoder(ids, cache=cache)
+    assert logits.shape == (1, 4, t.vocab_size) and logits.dtype == torch.bfloat16
+    cache.offset = 4                                                       # caller-maintained (generate.py:275)
+    assert len(cache.keys) == t.num_hidden_layers
+    assert cache.keys[0].shape == (1, t.num_key_value_heads, 4, t.head_dim)
+    model._decoder(torch.tensor([[7]]), cache=cache)
+    cache.offset += 1
+    assert cache.values[-1].shape == (1, t.num_key_value_heads, 5, t.head_dim)
+    m = create_additive_causal_mask(3, offset=2)
+    assert m.shape == (3, 5)
+    assert m[0].tolist() == [0.0, 0.0, 0.0, -1e9, -1e9] and m[2].tolist() == [0.0] * 5
+    # tied head: logits = norm(h) @ embed^T -> a one-hot-like check through the public embedding (test_decoder.py:228-247)
+    assert model._decoder.embed_tokens.weight.shape == (t.vocab_size, t.hidden_size)
+
+
+def test_log_mel_public_function(dev):
+    """reference tests/test_audio.py:41-95 against the HIP frontend."""
+    import qwen3_asr_mlx_amd as q
+    one_s = q.log_mel_spectrogram(signal("noise", 16000))
+    assert isinstance(one_s, torch.Tensor) and one_s.is_cuda and one_s.dtype == torch.float32
+    assert one_s.shape == (128, 100)                                       # 1 s -> exactly 100 frames
+    assert q.log_mel_spectrogram(signal("noise", 8000)).shape == (128, 50)
+    sil = q.log_mel_spectrogram(np.zeros(16000, dtype=np.float32))
+    assert torch.allclose(sil, torch.full_like(sil, -1.5), atol=1e-6)
+    assert float(one_s.max() - one_s.min()) <= 2.0 + 1e-6
+    with pytest.raises(NotImplementedError):
+        q.log_mel_spectrogram(signal("noise", 16000), n_fft=512)
+
+
+def test_generate_reference_signature(dev, small):
+    """generate()/prepare_inputs()/sample() keep the reference call shapes (test_generate.py:201-242)."""
+    import oracle
+    import qwen3_asr_mlx_amd as q
+    cfg, state, model = small
+    mel = q.log_mel_spectrogram(signal("speechlike", 32000))
+    enc_out = model._encoder(mel)                                          # (1, N, H)
+    prompt = q.build_prompt(enc_out.shape[1], [6364])
+    toks = q.generate(model._decoder, enc_out, prompt, max_tokens=6)
+    assert isinstance(toks, list) and len(toks) == 6 and all(isinstance(t, int) for t in toks)
+    assert q.generate(model._decoder, enc_out, prompt, max_tokens=1) == toks[:1]
+    with pytest.raises(ValueError, match="does not match"):
+        q.generate(model._decoder, enc_out[:, :-1], prompt, max_tokens=2)
+    text_only = q.prepare_inputs(torch.zeros(1, 0, cfg.text_decoder.hidden_size), [1, 2, 3, 4], model._decoder.embed_tokens)
+    assert text_only.shape == (1, 4, cfg.text_decoder.hidden_size)
+    assert torch.equal(text_only[0], model._decoder.embed_tokens([1, 2, 3, 4]))
