@@ -15,6 +15,7 @@
 // SwiGLU pair (gate, up) of a feature sits in the same lane and register.
 // Bound: MFMA (dense bf16 peak 2.5 PFLOP/s); algorithmic flops = 2*M*N*K.
 #include "common.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -38,10 +39,11 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + (
 
 // Epilogue shared by both GEMM kernels.  A lane holds, for accumulator tile (j, i): output row
 // m = m_base + 16 i + li and the 4 consecutive columns n = n_base + 16 j + 4 g + r.
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m_base, int n_base, int n0, int wn,
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n_base, int n0, int wn,
                                               int g, int li) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
         const int m = m_base + i * 16 + li;
         if (m >= p.M) continue;
         long orow = m;
@@ -210,11 +212,147 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, n0, wn, g, li);
+    gemm_epilogue<4>(p, acc, m0 + wm * 64, n0 + wn * 64, n0, wn, g, li);
+}
+
+// ---------------------------------------------------------------------------
+// 256x256x64 tile for grids with >= 6 tiles per CU: 8 waves (2 x 4), each 128 x 64 = 8 x 4 MFMA tiles.
+// Same register-staged, XOR-swizzled, double-buffered structure as the 128^2 kernel, but per MFMA half
+// the LDS store bytes and 3/4 of the LDS read bytes: at 128^2 the LDS stores, the LDS reads and the MFMAs of a
+// K step were measured NOT to overlap (ablation in profiles/), so the time per flop follows the LDS bytes per flop.
+// 128 KiB of LDS, one workgroup per CU, 2 waves per SIMD.
+// ---------------------------------------------------------------------------
+#define G2_T 256
+
+template <int CONV>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];          // [2 stages][A 32 KiB | W 32 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + G2_T - 1) / G2_T, tiles_m = (p.M + G2_T - 1) / G2_T;
+    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    const int group = GROUP_M * tiles_n;
+    const int first_m = (t / group) * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (int)(t % group) % gm;
+    const int tn = (int)(t % group) / gm;
+    const int m0 = tm * G2_T, n0 = tn * G2_T;
+
+    const int slot = tid & 7, lrow = tid >> 3;                             // 64 rows per pass, 4 passes per operand
+    long a_base[4], w_base[4];
+    int a_ih0[4], a_iw0[4];
+    bool a_ok[4], w_ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int am = m0 + lrow + 64 * q;
+        a_ok[q] = am < p.M;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int img = am / hw, rem = am - img * hw;
+            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+            a_ih0[q] = 2 * oh - 1;
+            a_iw0[q] = 2 * ow - 1;
+            a_base[q] = (long)img * p.Hin * p.Win * p.Cin;
+        } else {
+            a_base[q] = (long)am * p.lda;
+            a_ih0[q] = a_iw0[q] = 0;
+        }
+        const int wn_ = n0 + lrow + 64 * q;
+        w_ok[q] = wn_ < p.N;
+        w_base[q] = (long)wn_ * p.ldw;
+    }
+    uint4 ra[4], rw[4];
+    auto load_tile = [&](int k0) {
+        const int k = k0 + slot * 8;
+        const bool kin = k < p.K;
+        int ci = 0, kh = 0, kw = 0;
+        if (CONV) {
+            const int tap = k / p.Cin;
+            ci = k - tap * p.Cin;
+            kh = tap / 3;
+            kw = tap - 3 * kh;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (CONV) {
+                const int ih = a_ih0[q] + kh, iw = a_iw0[q] + kw;
+                if (a_ok[q] && kin && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
+                    v = *reinterpret_cast<const uint4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + ci));
+            } else {
+                if (a_ok[q] && kin) v = *reinterpret_cast<const uint4*>(p.A + a_base[q] + k);
+            }
+            ra[q] = v;
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (w_ok[q] && kin) w = *reinterpret_cast<const uint4*>(p.W + w_base[q] + k);
+            rw[q] = w;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sa = smem2 + buf * (2 * G2_T * 128);
+        char* sw = sa + G2_T * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = lrow + 64 * q;
+            *reinterpret_cast<uint4*>(sa + lds_off(r, slot)) = ra[q];
+            *reinterpret_cast<uint4*>(sw + lds_off(r, slot)) = rw[q];
+        }
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = lane >> 4, li = lane & 15;
+    f32x4 acc[4][8];   // [j: n tile][i: m tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const char* sa = smem2 + buf * (2 * G2_T * 128);
+        const char* sw = sa + G2_T * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[4], af[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[j] = *reinterpret_cast<const bf16x8*>(sw + lds_off(wn * 64 + j * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 128 + i * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    gemm_epilogue<8>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, wn, g, li);
 }
 
 static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
     const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
+    const unsigned tiles256 = (unsigned)((p.M + G2_T - 1) / G2_T) * (unsigned)((p.N + G2_T - 1) / G2_T);
+    static int mode = -1;                                    // Q3ASR_GEMM=128|256 pins a tile size (A/B runs, tests)
+    if (mode < 0) { const char* e = getenv("Q3ASR_GEMM"); mode = e ? atoi(e) : 0; }
+    if (mode == 256 || (mode != 128 && tiles256 >= 6 * 256)) {       // measured: 1.17-1.2x on >= 6 tiles per CU, slower below
+        const size_t lds = 2 * 2 * G2_T * 128;
+        static bool attr_set = false;
+        if (!attr_set) {                                     // 128 KiB of dynamic LDS needs the opt-in (once per process)
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (conv) hipLaunchKernelGGL(gemm256_kernel<1>, dim3(tiles256), dim3(512), lds, s, p);
+        else hipLaunchKernelGGL(gemm256_kernel<0>, dim3(tiles256), dim3(512), lds, s, p);
+        return;
+    }
     if (conv) hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(tiles), dim3(256), 0, s, p);
 }
