@@ -370,3 +370,16 @@ def test_generate_reference_signature(dev, small):
     text_only = q.prepare_inputs(torch.zeros(1, 0, cfg.text_decoder.hidden_size), [1, 2, 3, 4], model._decoder.embed_tokens)
     assert text_only.shape == (1, 4, cfg.text_decoder.hidden_size)
     assert torch.equal(text_only[0], model._decoder.embed_tokens([1, 2, 3, 4]))
+
+
+def test_full_size_ragged_batch_equals_singles(dev, full):
+    """1.7B shapes, utterances of different lengths (ragged chunks, partial attention windows, different
+    prompt lengths and decode budgets) in one batch == each alone."""
+    cfg, state, model = full
+    xs = [signal("speechlike", 480000, seed=41), signal("speechlike", 80000, seed=42), signal("noise", 197520, seed=43),
+          signal("tone", 8000)]
+    budgets = [9, 14, 6, 11]
+    batched = model.generate_tokens(xs, budgets, "English")
+    assert [len(t) for t in batched] == budgets
+    for i in range(len(xs)):
+        assert model.generate_tokens([xs[i]], [budgets[i]], "English")[0] == batched[i]

@@ -1,0 +1,65 @@
+// Micro-benchmark: cost of an in-kernel grid barrier (arrive counter + generation flag, agent-scope fences)
+// against an empty launch, 256 workgroups x 512 threads.  Build: hipcc --offload-arch=gfx950 -O3 gridbar.hip -o gridbar
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+__global__ __launch_bounds__(512) void empty_kernel(int* sink) {
+    if (sink && threadIdx.x == 9999) *sink = 1;
+}
+
+// counter c, generation gen: last arriver resets c and bumps gen; others poll gen (bounded)
+__device__ __forceinline__ bool grid_barrier(int* c, int* gen, int nwg, int gen0) {
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nwg - 1) {
+            __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gen, gen0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 2000000) { ok = false; break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return ok;
+}
+
+__global__ __launch_bounds__(512) void barrier_kernel(int* c, int* gen, int nbar, int* fail) {
+    for (int b = 0; b < nbar; ++b) {
+        const int gen0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every workgroup must read gen0 before the last one arrives: guaranteed, arrival follows the read in program order
+        if (!grid_barrier(c, gen, gridDim.x, gen0) && threadIdx.x == 0) atomicAdd(fail, 1);
+    }
+}
+
+int main() {
+    int *c, *gen, *fail;
+    hipMalloc(&c, 4); hipMalloc(&gen, 4); hipMalloc(&fail, 4);
+    hipMemset(c, 0, 4); hipMemset(gen, 0, 4); hipMemset(fail, 0, 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms;
+    const int R = 200;
+    for (int nwg : {256, 512}) {
+        for (int w = 0; w < 5; ++w) hipLaunchKernelGGL(empty_kernel, dim3(nwg), dim3(512), 0, 0, nullptr);
+        hipEventRecord(e0); for (int r = 0; r < R; ++r) hipLaunchKernelGGL(empty_kernel, dim3(nwg), dim3(512), 0, 0, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        printf("nwg=%d empty launch: %.2f us\n", nwg, 1e3 * ms / R);
+        if (nwg > 256) continue;                              // 512 x 512 threads are not co-resident on 256 CUs at 1 WG/CU? (they are: 2/CU) -- keep to 256
+        for (int nbar : {1, 2, 4, 8}) {
+            for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(barrier_kernel, dim3(nwg), dim3(512), 0, 0, c, gen, nbar, fail);
+            hipEventRecord(e0); for (int r = 0; r < R; ++r) hipLaunchKernelGGL(barrier_kernel, dim3(nwg), dim3(512), 0, 0, c, gen, nbar, fail);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            int f; hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost);
+            printf("nwg=%d barriers=%d: %.2f us per launch (fail=%d)\n", nwg, nbar, 1e3 * ms / R, f);
+        }
+    }
+    return 0;
+}
