@@ -246,6 +246,64 @@ def main() -> None:
                           "workload": f"batch=1, {args.clip_seconds:g} s clip, {args.ndec} decoded tokens"}
         log(f"batch-1 latency p50 {line['batch1']['p50_latency_ms']:.1f} ms")
     if world == 1:
+        # ---- per-stage time of one step against each stage's own roofline (SURVEY.md section 8d work figures)
+        from qwen3_asr_mlx_amd.generate import _merge, _side_stream
+        from qwen3_asr_mlx_amd.tokenizer import build_prompt
+        dec_, enc_ = model._decoder, model._encoder
+        fe = q.audio.get_frontend(dev)
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            return r, time.perf_counter() - s0
+
+        (mel, n_frames), t_mel = timed(lambda: fe(audio, lens_dev, lens))
+        (feats, tok_counts), t_enc = timed(lambda: enc_.forward_batch(mel, n_frames))
+        prompts = [build_prompt(nt, [6364]) for nt in tok_counts]
+        seq_lens = [len(p_) for p_ in prompts]
+        Lmax = (max(seq_lens) + args.ndec + 63) // 64 * 64
+        cache = dec_.batch_cache(B, Lmax)
+        ws = dec_.workspace(B, args.ndec)
+        sampling = {"temperature": 0.0, "top_p": 1.0, "top_k": 0, "repetition_penalty": 1.2, "repetition_context_size": 100, "seed": 0}
+
+        def prefill():
+            ws.n_gen.zero_(); ws.finished.zero_()
+            ws.pos.copy_(torch.tensor([t_ - 1 for t_ in seq_lens], dtype=torch.int32))
+            ws.max_new.copy_(torch.tensor(budgets, dtype=torch.int32))
+            emb = _merge(feats, prompts, tok_counts, dec_)
+            dec_.prefill(emb, seq_lens, cache, logits_out=ws.logits)
+            dec_.sample_step(ws, ws.logits, sampling)
+        _, t_pre = timed(prefill)
+
+        def decode():
+            side = _side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dec_.decode_step(ws, cache, sampling)
+                dec_.capture_step(ws, cache, sampling)
+                for _ in range(args.ndec - 2):
+                    dec_.replay_step(ws)
+            torch.cuda.current_stream().wait_stream(side)
+        _, t_dec = timed(decode)
+        secs = args.clip_seconds / 30.0
+        T_avg = sum(seq_lens) / B
+        l_bar = T_avg + args.ndec / 2.0
+        w_b = 2 if args.weights == "bf16" else 1
+        dec_bytes = (args.ndec - 1) * (w_b * 1.7205e9 + B * l_bar * 114688)
+        line["stages"] = {
+            "mel_ms": 1e3 * t_mel,
+            "encoder_ms": 1e3 * t_enc, "encoder_tflops": B * 374.1e9 * secs / t_enc / 1e12,
+            "encoder_frac_of_2.5PF": B * 374.1e9 * secs / t_enc / 2.5e15,
+            "prefill_ms": 1e3 * t_pre, "prefill_tflops": B * 1170e9 * (T_avg / 408.0) / t_pre / 1e12,
+            "prefill_frac_of_2.5PF": B * 1170e9 * (T_avg / 408.0) / t_pre / 2.5e15,
+            "decode_ms": 1e3 * t_dec, "decode_ms_per_token": 1e3 * t_dec / (args.ndec - 1),
+            "decode_GBps": dec_bytes / t_dec / 1e9, "decode_frac_of_8TBps": dec_bytes / t_dec / 8e12,
+            "note": "one step re-run stage by stage with a device sync between stages; work figures: SURVEY.md 8d "
+                    "(encoder 374.1 GFLOP and prefill 1,170 GFLOP per 30 s clip, decode 3.441 GB weights + B*L*114,688 B KV per token)",
+        }
+        log("stages: " + ", ".join(f"{k}={v:.1f}" for k, v in line["stages"].items() if k.endswith("_ms")))
         # ---- roofline of the dominant kernel (decode weight streaming: skinny3_kernel).  HIP events on the
         # launch stream around R back-to-back "GEMM-only" decode steps: exactly the 113 weight-streaming
         # launches of a step (4 per layer over all 28 layers' distinct weights, so 3.4 GB per step and no

@@ -376,7 +376,8 @@ class TextDecoder:
     # ------------------------------------------------------------------ hipGraph
     def capture_step(self, ws: DecodeWorkspace, cache: KVCache, sampling: dict) -> None:
         import torch
-        key = (id(cache.k), cache.max_len, tuple(sorted(sampling.items())))
+        # the graph bakes raw pointers: key it on the addresses it captured, not on Python object identity
+        key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.max_len, tuple(sorted(sampling.items())))
         if ws.graph is not None and ws.graph_key == key:
             return
         if ws.graph is not None:
