@@ -383,3 +383,26 @@ def test_full_size_ragged_batch_equals_singles(dev, full):
     assert [len(t) for t in batched] == budgets
     for i in range(len(xs)):
         assert model.generate_tokens([xs[i]], [budgets[i]], "English")[0] == batched[i]
+
+
+def test_run_sharded_over_rccl_world1(dev, small):
+    """The DP scatter/gather path on the real backend (RCCL, device tensors) at world size 1: same tokens as the
+    direct call.  (More ranks are covered with gloo in tests/test_dist_cpu.py; 8 GPUs only exist at the driver.)"""
+    import os
+    import torch.distributed as dist
+    from qwen3_asr_mlx_amd import dist as qd
+    cfg, state, model = small
+    xs = [signal("speechlike", 48000, seed=61), signal("noise", 16000, seed=62), signal("speechlike", 80000, seed=63)]
+    budgets = [5, 7, 4]
+    want = model.generate_tokens(xs, budgets, "English")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        got = qd.run_sharded(lambda a, m: model.generate_tokens(a, m, "English"), xs, budgets, device=dev)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert got == want
