@@ -98,8 +98,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
 }
 
-template <int CONV>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+template <int CONV, bool FAST = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * BM * BK * 2];   // A0 | W0 | A1 | W1, 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
@@ -137,7 +137,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         w_base[q] = (long)wn_ * p.ldw;
     }
 
-    uint4 ra[4], rw[4];
+    // FAST (plain GEMM, K % 64 == 0, operands < 4 GiB): edge rows are clamped instead of predicated (their outputs are
+    // masked in the epilogue) and every load is uniform base + 32-bit lane offset: no branches, no 64-bit VALU per step.
+    unsigned fa_off[4] = {0, 0, 0, 0}, fw_off[4] = {0, 0, 0, 0};
+    if constexpr (FAST) {
+        fa_off[0] = (unsigned)(((long)min(m0 + lrow, p.M - 1) * p.lda + slot * 8) * 2);
+        fa_off[1] = (unsigned)(((long)min(m0 + lrow + 32, p.M - 1) * p.lda + slot * 8) * 2);
+        fa_off[2] = (unsigned)(((long)min(m0 + lrow + 64, p.M - 1) * p.lda + slot * 8) * 2);
+        fa_off[3] = (unsigned)(((long)min(m0 + lrow + 96, p.M - 1) * p.lda + slot * 8) * 2);
+        fw_off[0] = (unsigned)(((long)min(n0 + lrow, p.N - 1) * p.ldw + slot * 8) * 2);
+        fw_off[1] = (unsigned)(((long)min(n0 + lrow + 32, p.N - 1) * p.ldw + slot * 8) * 2);
+        fw_off[2] = (unsigned)(((long)min(n0 + lrow + 64, p.N - 1) * p.ldw + slot * 8) * 2);
+        fw_off[3] = (unsigned)(((long)min(n0 + lrow + 96, p.N - 1) * p.ldw + slot * 8) * 2);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[4], rw[4];
     auto load_tile = [&](int k0) {
         const int k = k0 + slot * 8;
         const bool kin = k < p.K;
@@ -151,28 +165,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint4 v = make_uint4(0, 0, 0, 0);
+            u32x4 v = {0u, 0u, 0u, 0u};
             if (CONV) {
                 const int ih = a_ih0[q] + kh, iw = a_iw0[q] + kw;
                 if (a_ok[q] && kin && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
-                    v = *reinterpret_cast<const uint4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + tap_off));
+                    v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + tap_off));
             } else {
-                if (a_ok[q] && kin) v = *reinterpret_cast<const uint4*>(p.A + a_base[q] + k);
+                if (a_ok[q] && kin) v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + k);
             }
             ra[q] = v;
-            uint4 w = make_uint4(0, 0, 0, 0);
-            if (w_ok[q] && kin) w = *reinterpret_cast<const uint4*>(p.W + w_base[q] + k);
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if (w_ok[q] && kin) w = *reinterpret_cast<const u32x4*>(p.W + w_base[q] + k);
             rw[q] = w;
         }
     };
+#define Q3_LOAD_FAST(K0)                                                                      \
+    {                                                                                         \
+        const char* pa_ = reinterpret_cast<const char*>(p.A) + (long)(K0) * 2;                \
+        const char* pw_ = reinterpret_cast<const char*>(p.W) + (long)(K0) * 2;                \
+        ra[0] = *reinterpret_cast<const u32x4*>(pa_ + fa_off[0]);                             \
+        ra[1] = *reinterpret_cast<const u32x4*>(pa_ + fa_off[1]);                             \
+        ra[2] = *reinterpret_cast<const u32x4*>(pa_ + fa_off[2]);                             \
+        ra[3] = *reinterpret_cast<const u32x4*>(pa_ + fa_off[3]);                             \
+        rw[0] = *reinterpret_cast<const u32x4*>(pw_ + fw_off[0]);                             \
+        rw[1] = *reinterpret_cast<const u32x4*>(pw_ + fw_off[1]);                             \
+        rw[2] = *reinterpret_cast<const u32x4*>(pw_ + fw_off[2]);                             \
+        rw[3] = *reinterpret_cast<const u32x4*>(pw_ + fw_off[3]);                             \
+    }
     auto store_tile = [&](int buf) {
         char* sa = smem + buf * (2 * BM * BK * 2);
         char* sw = sa + BM * BK * 2;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = lrow + 32 * q;
-            *reinterpret_cast<uint4*>(sa + lds_off(r, slot)) = ra[q];
-            *reinterpret_cast<uint4*>(sw + lds_off(r, slot)) = rw[q];
+            *reinterpret_cast<u32x4*>(sa + lds_off(r, slot)) = ra[q];
+            *reinterpret_cast<u32x4*>(sw + lds_off(r, slot)) = rw[q];
         }
     };
 
@@ -185,12 +212,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
+    if constexpr (FAST) Q3_LOAD_FAST(0) else load_tile(0);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        if (kt + 1 < nk) {
+            if constexpr (FAST) Q3_LOAD_FAST((kt + 1) * BK) else load_tile((kt + 1) * BK);
+        }
         const char* sa = smem + buf * (2 * BM * BK * 2);
         const char* sw = sa + BM * BK * 2;
 #pragma unroll
@@ -224,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 // ---------------------------------------------------------------------------
 #define G2_T 256
 
-template <int CONV>
+template <int CONV, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem2[];          // [2 stages][A 32 KiB | W 32 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -260,7 +289,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         w_ok[q] = wn_ < p.N;
         w_base[q] = (long)wn_ * p.ldw;
     }
-    uint4 ra[4], rw[4];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[4], rw[4];
+    unsigned fa_off[4] = {0, 0, 0, 0}, fw_off[4] = {0, 0, 0, 0};   // FAST: clamped rows, uniform base + 32-bit lane offset
+    if constexpr (FAST) {
+        fa_off[0] = (unsigned)(((long)min(m0 + lrow, p.M - 1) * p.lda + slot * 8) * 2);
+        fa_off[1] = (unsigned)(((long)min(m0 + lrow + 64, p.M - 1) * p.lda + slot * 8) * 2);
+        fa_off[2] = (unsigned)(((long)min(m0 + lrow + 128, p.M - 1) * p.lda + slot * 8) * 2);
+        fa_off[3] = (unsigned)(((long)min(m0 + lrow + 192, p.M - 1) * p.lda + slot * 8) * 2);
+        fw_off[0] = (unsigned)(((long)min(n0 + lrow, p.N - 1) * p.ldw + slot * 8) * 2);
+        fw_off[1] = (unsigned)(((long)min(n0 + lrow + 64, p.N - 1) * p.ldw + slot * 8) * 2);
+        fw_off[2] = (unsigned)(((long)min(n0 + lrow + 128, p.N - 1) * p.ldw + slot * 8) * 2);
+        fw_off[3] = (unsigned)(((long)min(n0 + lrow + 192, p.N - 1) * p.ldw + slot * 8) * 2);
+    }
     auto load_tile = [&](int k0) {
         const int k = k0 + slot * 8;
         const bool kin = k < p.K;
@@ -273,17 +314,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint4 v = make_uint4(0, 0, 0, 0);
+            u32x4 v = {0u, 0u, 0u, 0u};
             if (CONV) {
                 const int ih = a_ih0[q] + kh, iw = a_iw0[q] + kw;
                 if (a_ok[q] && kin && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
-                    v = *reinterpret_cast<const uint4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + ci));
+                    v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + ci));
             } else {
-                if (a_ok[q] && kin) v = *reinterpret_cast<const uint4*>(p.A + a_base[q] + k);
+                if (a_ok[q] && kin) v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + k);
             }
             ra[q] = v;
-            uint4 w = make_uint4(0, 0, 0, 0);
-            if (w_ok[q] && kin) w = *reinterpret_cast<const uint4*>(p.W + w_base[q] + k);
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if (w_ok[q] && kin) w = *reinterpret_cast<const u32x4*>(p.W + w_base[q] + k);
             rw[q] = w;
         }
     };
@@ -293,8 +334,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = lrow + 64 * q;
-            *reinterpret_cast<uint4*>(sa + lds_off(r, slot)) = ra[q];
-            *reinterpret_cast<uint4*>(sw + lds_off(r, slot)) = rw[q];
+            *reinterpret_cast<u32x4*>(sa + lds_off(r, slot)) = ra[q];
+            *reinterpret_cast<u32x4*>(sw + lds_off(r, slot)) = rw[q];
         }
     };
 
@@ -307,12 +348,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
+    if constexpr (FAST) Q3_LOAD_FAST(0) else load_tile(0);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        if (kt + 1 < nk) {
+            if constexpr (FAST) Q3_LOAD_FAST((kt + 1) * BK) else load_tile((kt + 1) * BK);
+        }
         const char* sa = smem2 + buf * (2 * G2_T * 128);
         const char* sw = sa + G2_T * 128;
 #pragma unroll
@@ -338,6 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
 static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
     const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
+    const bool fast = !conv && p.K % BK == 0 && (long)p.M * p.lda < (1L << 31) && (long)p.N * p.ldw < (1L << 31);
     const unsigned tiles256 = (unsigned)((p.M + G2_T - 1) / G2_T) * (unsigned)((p.N + G2_T - 1) / G2_T);
     static int mode = -1;                                    // Q3ASR_GEMM=128|256 pins a tile size (A/B runs, tests)
     if (mode < 0) { const char* e = getenv("Q3ASR_GEMM"); mode = e ? atoi(e) : 0; }
@@ -347,13 +391,16 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
         if (!attr_set) {                                     // 128 KiB of dynamic LDS needs the opt-in (once per process)
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm256_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
         if (conv) hipLaunchKernelGGL(gemm256_kernel<1>, dim3(tiles256), dim3(512), lds, s, p);
+        else if (fast) hipLaunchKernelGGL((gemm256_kernel<0, true>), dim3(tiles256), dim3(512), lds, s, p);
         else hipLaunchKernelGGL(gemm256_kernel<0>, dim3(tiles256), dim3(512), lds, s, p);
         return;
     }
     if (conv) hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), 0, s, p);
+    else if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<0, true>), dim3(tiles), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_bf16_kernel<0>, dim3(tiles), dim3(256), 0, s, p);
 }
 
