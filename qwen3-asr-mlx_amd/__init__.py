@@ -2,21 +2,26 @@
 gabrimatic/qwen3-asr-mlx over hand-written HIP kernels (libq3asr_hip.so).
 
 Import name: ``qwen3_asr_mlx_amd`` (this directory is ``qwen3-asr-mlx_amd``; the repo-root module
-``qwen3_asr_mlx_amd.py`` maps one onto the other).  Same 20 exports as reference __init__.py:16-37.
+``qwen3_asr_mlx_amd.py`` maps one onto the other).  The public names are the reference's 20 exports
+(reference __init__.py:16-37), in its order, each bound from the module that implements it here.
 """
+from . import _lib, audio, config, decoder, encoder, generate as _generate, model, ops, tokenizer  # noqa: F401
+
 __version__ = "0.1.0"
 
-from .audio import load_audio, log_mel_spectrogram
-from .config import AudioEncoderConfig, ModelConfig, TextDecoderConfig
-from .decoder import KVCache, TextDecoder, load_decoder_weights
-from .encoder import AudioEncoder, load_encoder_weights
-from .generate import generate, generate_batch, prepare_inputs, sample
-from .model import LANGUAGE_MAP, Qwen3ASR, TranscriptionResult
-from .tokenizer import Tokenizer, build_prompt, parse_output
-
-__all__ = [
-    "__version__", "load_audio", "log_mel_spectrogram", "AudioEncoderConfig", "TextDecoderConfig", "ModelConfig",
-    "AudioEncoder", "load_encoder_weights", "KVCache", "TextDecoder", "load_decoder_weights", "generate",
-    "prepare_inputs", "sample", "Tokenizer", "build_prompt", "parse_output", "Qwen3ASR", "TranscriptionResult",
-    "LANGUAGE_MAP",
-]
+_PUBLIC = (
+    (audio, ("load_audio", "log_mel_spectrogram")),
+    (config, ("AudioEncoderConfig", "TextDecoderConfig", "ModelConfig")),
+    (encoder, ("AudioEncoder", "load_encoder_weights")),
+    (decoder, ("KVCache", "TextDecoder", "load_decoder_weights")),
+    (_generate, ("generate", "prepare_inputs", "sample")),
+    (tokenizer, ("Tokenizer", "build_prompt", "parse_output")),
+    (model, ("Qwen3ASR", "TranscriptionResult", "LANGUAGE_MAP")),
+)
+__all__ = ["__version__"]
+for _mod, _names in _PUBLIC:
+    for _n in _names:
+        globals()[_n] = getattr(_mod, _n)
+        __all__.append(_n)
+generate_batch = _generate.generate_batch          # batch API (new; not part of the reference surface)
+del _mod, _names, _n
