@@ -124,3 +124,99 @@ def test_bookkeeping_eos_budget_and_finished(dev):
     assert out[2, 0].item() == -1 and cur[2].item() == 42 and n_gen[2].item() == 0    # already finished: untouched
     step()
     assert n_gen.tolist() == [1, 1, 0] and out[0, 1].item() == -1
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-vocabulary rows through the C-ABI, many independent draws per launch (row b draws with Philox
+# counter (n_gen, b), so B copies of one row are B independent draws)
+def _draw_many(row_bf16, n_draws, temperature, top_p=1.0, top_k=0, B=64):
+    from qwen3_asr_mlx_amd import ops
+    dev = row_bf16.device
+    V = row_bf16.numel()
+    logits = row_bf16.reshape(1, V).repeat(B, 1).contiguous()
+    out = []
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
+    for it in range((n_draws + B - 1) // B):
+        out_tokens = torch.zeros(B, 1, dtype=torch.int32, device=dev)
+        n_gen, fin, cur, pos, mx = i32([0] * B), i32([0] * B), i32([0] * B), i32([0] * B), i32([1] * B)
+        ops.call("q3asr_sample_step", ops.ptr(logits), V, B, V, ops.ptr(out_tokens), 1, ops.ptr(n_gen), ops.ptr(fin),
+                 ops.ptr(cur), ops.ptr(pos), ops.ptr(mx), float(temperature), float(top_p), int(top_k), 1.0, 1,
+                 1000 + it, -1, -1, ops.sp())
+        out += cur.tolist()
+    return np.array(out[:n_draws])
+
+
+def _oracle_probs(row_bf16, temperature, top_p, top_k):
+    import oracle
+    x = (row_bf16.float().cpu() / torch.tensor(temperature).to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    if top_k > 0:
+        x = oracle.top_k_filter(x, top_k)
+    if top_p < 1.0:
+        x = oracle.top_p_filter(x, top_p)
+    return torch.softmax(x.double(), dim=-1).numpy()
+
+
+@pytest.mark.parametrize("temperature,top_p,top_k", [(0.7, 0.9, 0), (1.0, 1.0, 50), (0.7, 0.8, 40), (1.3, 0.5, 0),
+                                                     (1.0, 1.0, 0), (0.5, 0.95, 2000)])
+def test_full_vocab_draws_follow_the_filtered_softmax(dev, temperature, top_p, top_k):
+    """V = 151936 (Qwen3-ASR's vocabulary), gaussian logits (heavy bf16 ties): every draw lies in the oracle's kept
+    set, and the draws' mean log-probability matches the kept law's negative entropy."""
+    V = 151936
+    g = torch.Generator().manual_seed(11)
+    row = (torch.randn(V, generator=g) * 2.5).to(torch.bfloat16).to(dev)
+    probs = _oracle_probs(row, temperature, top_p, top_k)
+    n = 4096
+    draws = _draw_many(row, n, temperature, top_p, top_k)
+    kept = probs > 0
+    # The nucleus boundary may sit inside a tie; how many of the tied logits survive is decided by (target - above) / p_tie,
+    # which the oracle evaluates with an fp32 softmax that sums to 1 + 1e-5 and the kernel with exact-key masses: they may
+    # differ by one tied token of probability ~1e-5.  Anything else outside the kept set is an error.
+    x = (row.float().cpu() / torch.tensor(temperature).to(torch.bfloat16).float()).to(torch.bfloat16).float().numpy()
+    outside = draws[~kept[draws]]
+    assert len(outside) <= 2 and (x[outside] == x[kept].min()).all(), ("draw outside the kept set", x[outside], x[kept].min())
+    draws = draws[kept[draws]]
+    logp = np.log(probs[kept])
+    mean, var = (probs[kept] * logp).sum(), (probs[kept] * logp ** 2).sum() - (probs[kept] * logp).sum() ** 2
+    got = np.log(probs[draws]).mean()
+    assert abs(got - mean) < 5 * np.sqrt(var / len(draws)) + 1e-3, (got, mean, np.sqrt(var / n))
+    if top_k and top_k <= 50:                                            # small kept set: all of it is seen, TV distance small
+        assert set(np.unique(draws)) == set(np.nonzero(kept)[0])
+        counts = np.bincount(draws, minlength=V)
+        assert 0.5 * np.abs(counts / n - probs).sum() < 0.08
+
+
+def test_full_vocab_nucleus_cuts_inside_a_tie_in_index_order(dev):
+    """10 logits at 5.0, 1000 tied at 4.0 scattered over the vocabulary, the rest far below: the nucleus boundary falls
+    inside the tie and keeps its first tokens in index order (stable sort + exclusive cumsum, generate.py:152-163)."""
+    import oracle
+    V = 151936
+    g = torch.Generator().manual_seed(5)
+    perm = torch.randperm(V, generator=g)
+    row = torch.full((V,), -20.0)
+    row[perm[:10]] = 5.0
+    row[perm[10:1010]] = 4.0
+    row = row.to(torch.bfloat16).to(dev)
+    for top_p in (0.3, 0.6):
+        keep = torch.isfinite(oracle.top_p_filter(row.float().cpu(), top_p)).nonzero().flatten().numpy()
+        assert 10 < len(keep) < 1010
+        draws = _draw_many(row, 16384, 1.0, top_p=top_p)
+        assert set(np.unique(draws)) == set(keep), (top_p, len(set(draws)), len(keep))
+
+
+def test_full_vocab_top_k_keeps_ties_at_threshold(dev):
+    V = 151936
+    row = torch.full((V,), -3.0)
+    row[[7, 70000, 151935]] = 2.0
+    row[[100, 101, 90000, 151000]] = 1.0                                 # k = 5 lands inside this tie: all four stay
+    row = row.to(torch.bfloat16).to(dev)
+    draws = _draw_many(row, 2048, 1.0, top_k=5)
+    assert set(np.unique(draws)) == {7, 70000, 151935, 100, 101, 90000, 151000}
+
+
+def test_sampling_is_reproducible_for_a_seed(dev):
+    V = 151936
+    g = torch.Generator().manual_seed(2)
+    row = (torch.randn(V, generator=g) * 3).to(torch.bfloat16).to(dev)
+    a = _draw_many(row, 256, 0.8, top_p=0.9, top_k=100)
+    b = _draw_many(row, 256, 0.8, top_p=0.9, top_k=100)
+    assert (a == b).all() and len(set(a.tolist())) > 1
