@@ -116,11 +116,15 @@ int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t slab_stride, 
 int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_out, const void* w, void* x16, int M, int N,
                          float eps, void* stream);
 /* decode attention with decoder.py:144-156 (QK-RMSNorm, RoPE, cache append) fused into its prologue;
- * input: the qkv projection as n_slabs fp32 slabs [n_slabs][B][ld]; output att in X16 layout. */
+ * input: the qkv projection as n_slabs fp32 slabs [n_slabs][B][ld]; output att in X16 layout.
+ * The cache is processed in 512-token chunks, one workgroup each; sequences longer than a chunk are merged
+ * through `workspace` (q3asr_attn_decode_fused_workspace(B, nkv, Lmax) bytes, zero-filled once by the caller,
+ * left zeroed/ready by every launch; launches sharing a workspace must be ordered on one stream). */
+int64_t q3asr_attn_decode_fused_workspace(int B, int nkv, int Lmax);
 int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_slabs, int64_t slab_stride, const void* qn_w,
                             const void* kn_w, const float* inv_freq, float eps, void* k_cache, void* v_cache,
                             const int32_t* pos, void* out16, int B, int nh, int nkv, int head_dim, int Lmax,
-                            float scale, void* stream);
+                            float scale, void* workspace, void* stream);
 int q3asr_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
                       int B, int nh, int nkv, int head_dim, int Lmax, float scale, void* stream);
 

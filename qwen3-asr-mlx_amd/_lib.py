@@ -32,7 +32,8 @@ _SIGS = {
     "q3asr_skinny3_gemm": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_slab_resnorm_x16": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_embed_norm_x16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
-    "q3asr_attn_decode_fused": [_vp, _i64, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
+    "q3asr_attn_decode_fused_workspace": [_i, _i, _i],
+    "q3asr_attn_decode_fused": [_vp, _i64, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "q3asr_slab_residual_rmsnorm": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_slab_swiglu": [_vp, _i, _i64, _vp, _i, _i, _vp],
     "q3asr_attn_decode": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
@@ -46,7 +47,7 @@ _SIGS = {
     "q3asr_event_elapsed_ms": [_vp, _vp, C.POINTER(_f)],
     "q3asr_event_destroy": [_vp],
 }
-_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p}
+_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p, "q3asr_attn_decode_fused_workspace": C.c_int64}
 EXPORTS = tuple(_SIGS)
 
 

@@ -384,26 +384,46 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_o
 // (decoder.py:140-163 at T = 1).  The qkv projection arrives as S fp32 split-K slabs [S][B][(nh+2nkv)*128];
 // their sum is rounded to bf16 (the projection's output dtype).  The attention output (the o
 // projection's operand) is written in X16 layout.
-// Workgroup (kv head, sequence): waves 0..3 normalise/rotate q0, q1, k and pass v through; the new
-// k/v go to the cache AND to LDS (the token attends to itself without a global round trip).
+//
+// Workgroup (kv head, sequence, 512-token chunk of the cache).  Waves 0,1 normalise/rotate the two query
+// heads; in the chunk that holds the new token waves 2,3 do the same for k and pass v through, and the new
+// k/v go to the cache AND to LDS (the token attends to itself without a global round trip).  A chunk is
+// swept in 128-token batches through a register double buffer (2 x 64 KiB in flight, the first batch issued
+// before the prologue); 32 token slots keep online-softmax partials, merged through LDS.
+// Sequences longer than one chunk: every chunk writes (max, sum, numerator[128]) per head to the workspace,
+// and the LAST workgroup to arrive (device-scope counter) merges the chunks in chunk order, so the result
+// depends only on the sequence, not on the batch, the cache capacity or the arrival order.
+// Chunks past the sequence's length exit at once: the grid is sized for the cache capacity because the
+// launch is captured in a graph while positions advance.
 // ---------------------------------------------------------------------------
+#define ADF_CHUNK 512
+#define ADF_PART (2 * 130)            // floats per (sequence, kv head, chunk): per head 128 numerators, max, sum
+
 __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
                                                                 const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
                                                                 const float* __restrict__ inv_freq, float eps,
                                                                 bf16* __restrict__ k_cache, bf16* __restrict__ v_cache,
                                                                 const int* __restrict__ pos_arr, bf16* __restrict__ out16,
-                                                                int MT, int nh, int nkv, int Lmax, float scale) {
+                                                                int MT, int nh, int nkv, int Lmax, float scale,
+                                                                float* part, int* counters, int nc, int G) {
     __shared__ float s_q[2][128];
     __shared__ __attribute__((aligned(16))) bf16 s_k[128], s_v[128];
     __shared__ float s_m[32][2], s_l[32][2];
     __shared__ __attribute__((aligned(16))) float s_acc[32][2][128];
+    __shared__ int s_ticket;
     const int kvh = blockIdx.x, b = blockIdx.y;
+    const int pos = pos_arr[b];
+    const int L = pos + 1, n_active = (L + ADF_CHUNK - 1) / ADF_CHUNK;
+    const int c_begin = blockIdx.z * G, c_end = min(c_begin + G, n_active);   // this workgroup's chunks
+    if (c_begin >= n_active) return;                                  // whole workgroup: no barrier is skipped
+    const int n_groups = (n_active + G - 1) / G;                      // workgroups active for this (sequence, kv head)
+    const bool owner = c_end == n_active;                             // the last chunk holds the new token
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
-    const int pos = pos_arr[b];
     bf16* Kb = k_cache + ((long)b * nkv + kvh) * Lmax * 128;
     bf16* Vb = v_cache + ((long)b * nkv + kvh) * Lmax * 128;
     const int slot = wave * 4 + g;                                    // 32 token slots per 32-token sweep
+    const int t0 = c_begin * ADF_CHUNK;
     bf16x8 kA[4], vA[4], kB[4], vB[4];
     const int t_last = pos > 0 ? pos - 1 : 0;                         // tokens >= pos are never read from the cache
 #define Q3_LOAD_BATCH(KK, VV, T0)                                                                   \
@@ -412,8 +432,8 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
         KK[u] = *reinterpret_cast<const bf16x8*>(Kb + (long)t_ * 128 + 8 * i);                      \
         VV[u] = *reinterpret_cast<const bf16x8*>(Vb + (long)t_ * 128 + 8 * i);                      \
     }
-    Q3_LOAD_BATCH(kA, vA, 0)
-    if (wave < 4) {
+    Q3_LOAD_BATCH(kA, vA, t0)
+    if (wave < 2 || (wave < 4 && owner)) {
         const int col = wave < 2 ? (2 * kvh + wave) * 128 : (wave == 2 ? (nh + kvh) * 128 : (nh + nkv + kvh) * 128);
         const float* src = qkv + (long)b * ld + col;
         float s1 = 0.f, s2 = 0.f;
@@ -493,42 +513,116 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             }                                                                                       \
         }                                                                                           \
     }
-    const int L = pos + 1;
-    for (int t0 = 0; t0 < L; t0 += 256) {                              // register double buffer: 2 x 64 KiB per workgroup in flight
-        if (t0 + 128 < L) { Q3_LOAD_BATCH(kB, vB, t0 + 128) }
-        Q3_COMPUTE(kA, vA, t0)
-        if (t0 + 256 < L) { Q3_LOAD_BATCH(kA, vA, t0 + 256) }
-        if (t0 + 128 < L) { Q3_COMPUTE(kB, vB, t0 + 128) }
+    const int t_end = min(L, c_end * ADF_CHUNK);
+    const int h = (tid >> 7) & 1, d = tid & 127;
+    float* my = part + (((long)b * nkv + kvh) * nc) * ADF_PART;
+    for (int tt = t0; tt < t_end; tt += 256) {                         // register double buffer: 2 x 64 KiB per workgroup in flight
+        if (tt + 128 < t_end) { Q3_LOAD_BATCH(kB, vB, tt + 128) }
+        Q3_COMPUTE(kA, vA, tt)
+        if (tt + 256 < t_end) { Q3_LOAD_BATCH(kA, vA, tt + 256) }
+        if (tt + 128 < t_end) { Q3_COMPUTE(kB, vB, tt + 128) }
+        if (((tt + 256) % ADF_CHUNK) != 0 && tt + 256 < t_end) continue;
+        // ---- end of a chunk: merge the 32 slots (the next chunk's first batch is already in flight)
+        if (i == 0) { s_m[slot][0] = m0; s_m[slot][1] = m1; s_l[slot][0] = l0; s_l[slot][1] = l1; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s_acc[slot][0][8 * i + e] = a0[e]; s_acc[slot][1][8 * i + e] = a1[e]; }
+        __syncthreads();
+        if (tid < 256) {
+            float Mx = -INFINITY, num = 0.f, den = 0.f;
+            for (int s = 0; s < 32; ++s) Mx = fmaxf(Mx, s_m[s][h]);
+            for (int s = 0; s < 32; ++s) {
+                const float w = __expf(s_m[s][h] - Mx);
+                num = fmaf(s_acc[s][h][d], w, num);
+                den = fmaf(s_l[s][h], w, den);
+            }
+            if (n_active == 1) {                                      // the whole sequence is this chunk
+                out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(num / den);
+            } else {
+                // Partials travel as device-scope (write-through) atomic stores and loads, so no cache-wide
+                // write-back or invalidate is needed.
+                float* dst = my + (long)(tt / ADF_CHUNK) * ADF_PART + h * 130;
+                __hip_atomic_store(dst + d, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d == 0) {
+                    __hip_atomic_store(dst + 128, Mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 129, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (tt + 256 < t_end) {                                       // another chunk follows: fresh slots
+            __syncthreads();
+            m0 = m1 = -INFINITY;
+            l0 = l1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+        }
     }
 #undef Q3_COMPUTE
 #undef Q3_LOAD_BATCH
-    if (i == 0) { s_m[slot][0] = m0; s_m[slot][1] = m1; s_l[slot][0] = l0; s_l[slot][1] = l1; }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s_acc[slot][0][8 * i + e] = a0[e]; s_acc[slot][1][8 * i + e] = a1[e]; }
+    if (n_active == 1) return;                                        // uniform
+    // Each wave waits for its own partial stores to be acknowledged, the barrier collects the waves, and only
+    // then is the ticket taken; the last workgroup to arrive merges every chunk of the sequence.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < 256) {
-        const int h = tid >> 7, d = tid & 127;
-        float Mx = -INFINITY;
-        for (int s = 0; s < 32; ++s) Mx = fmaxf(Mx, s_m[s][h]);
-        float num = 0.f, den = 0.f;
-        for (int s = 0; s < 32; ++s) {
-            const float w = __expf(s_m[s][h] - Mx);
-            num = fmaf(s_acc[s][h][d], w, num);
-            den = fmaf(s_l[s][h], w, den);
-        }
-        out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(num / den);
+    if (n_groups > 1) {
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(counters + b * nkv + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != n_groups - 1) return;                         // uniform
     }
+    if (tid < 256) {
+        float M = -INFINITY;
+        for (int c = 0; c < n_active; ++c)
+            M = fmaxf(M, __hip_atomic_load(my + (long)c * ADF_PART + h * 130 + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        float N = 0.f, D = 0.f;
+        for (int c = 0; c < n_active; ++c) {                          // chunk order, whoever merges
+            const float* src = my + (long)c * ADF_PART + h * 130;
+            const float w = __expf(__hip_atomic_load(src + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - M);
+            N = fmaf(__hip_atomic_load(src + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w, N);
+            D = fmaf(__hip_atomic_load(src + 129, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w, D);
+        }
+        out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(N / D);
+    }
+    if (n_groups > 1 && tid == 0)
+        __hip_atomic_store(counters + b * nkv + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
+
+// Chunks per workgroup for a launch: minimises rounds x (fixed cost + chunks x chunk time) (+ the cross-workgroup
+// merge when a sequence spans several workgroups), one 512-thread workgroup per CU, at the cache's capacity.
+// Any value gives the same bits (per-chunk partials, merged in chunk order); Q3ASR_ATTN_CHUNKS_PER_WG overrides.
+static int adf_chunks_per_wg(int pairs, int nc) {
+    static const int forced = [] { const char* e = getenv("Q3ASR_ATTN_CHUNKS_PER_WG"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced < nc ? forced : nc;
+    const float fixed_us = 8.f, chunk_us = 12.f, merge_us = 5.f;
+    int best = nc;
+    float best_cost = 1e30f;
+    for (int G = nc; G >= 1; --G) {
+        const int groups = (nc + G - 1) / G;
+        const int rounds = (pairs * groups + 255) / 256;
+        const float cost = rounds * (fixed_us + G * chunk_us) + (groups > 1 ? merge_us : 0.f);
+        if (cost < best_cost - 0.5f) { best_cost = cost; best = G; }
+    }
+    return best;
+}
+
+extern "C" int64_t q3asr_attn_decode_fused_workspace(int B, int nkv, int Lmax) {
+    if (B <= 0 || nkv <= 0 || Lmax <= 0) return 0;
+    const int64_t nc = (Lmax + ADF_CHUNK - 1) / ADF_CHUNK;
+    return ((int64_t)B * nkv * nc * ADF_PART + (int64_t)B * nkv) * 4;
 }
 
 extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_slabs, int64_t slab_stride, const void* qn_w, const void* kn_w, const float* inv_freq,
                                        float eps, void* k_cache, void* v_cache, const int32_t* pos, void* out, int B, int nh,
-                                       int nkv, int head_dim, int Lmax, float scale, void* stream) {
-    Q3_REQUIRE(qkv_slab && n_slabs > 0 && qn_w && kn_w && inv_freq && k_cache && v_cache && pos && out, "attn_decode_fused: null pointer");
+                                       int nkv, int head_dim, int Lmax, float scale, void* workspace, void* stream) {
+    Q3_REQUIRE(qkv_slab && n_slabs > 0 && qn_w && kn_w && inv_freq && k_cache && v_cache && pos && out && workspace, "attn_decode_fused: null pointer");
     Q3_REQUIRE(head_dim == 128 && nh == 2 * nkv, "attn_decode_fused: needs head_dim 128 and 2 query heads per kv head");
     Q3_REQUIRE(B > 0 && B <= 64 && Lmax > 0 && ld >= (int64_t)(nh + 2 * nkv) * 128, "attn_decode_fused: bad sizes");
     const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(nkv, B), dim3(512), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+    const int nc = (Lmax + ADF_CHUNK - 1) / ADF_CHUNK;
+    Q3_REQUIRE(nc <= 65535, "attn_decode_fused: Lmax=%d too long", Lmax);
+    float* part = (float*)workspace;
+    int* counters = (int*)(part + (int64_t)B * nkv * nc * ADF_PART);
+    const int G = adf_chunks_per_wg(B * nkv, nc);
+    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
                        (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
-                       nkv, Lmax, scale);
+                       nkv, Lmax, scale, part, counters, nc, G);
     return q3_check_launch("attn_decode_fused");
 }

@@ -26,6 +26,7 @@ class KVCache:
         self.v = None
         self.batch = 0
         self.max_len = 0
+        self.attn_ws = None        # q3asr_attn_decode_fused workspace (chunk partials + arrival counters), zeroed once
 
     def ensure(self, cfg: TextDecoderConfig, batch: int, max_len: int, device) -> None:
         import torch
@@ -38,6 +39,8 @@ class KVCache:
                 self.k[:, :, :, : old[2]] = old[0]
                 self.v[:, :, :, : old[2]] = old[1]
             self.batch, self.max_len = batch, max_len
+            nbytes = _lib.load().q3asr_attn_decode_fused_workspace(batch, cfg.num_key_value_heads, max_len)
+            self.attn_ws = torch.zeros((nbytes // 4,), dtype=torch.float32, device=device)
 
     @property
     def keys(self):
@@ -338,7 +341,7 @@ class TextDecoder:
             s_qkv = self._gemm3(ws, "qkv", ws.x16, L, "wqkv", qkvd, H, 0)
             ops.call("q3asr_attn_decode_fused", ops.ptr(ws.slab), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),
                      ops.ptr(w["inv_freq"]), eps, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(pos), ops.ptr(ws.att16),
-                     B, nh, nkv, hd, Lmax, scale, ops.sp())
+                     B, nh, nkv, hd, Lmax, scale, ops.ptr(cache.attn_ws), ops.sp())
             s_o = self._gemm3(ws, "o", ws.att16, L, "wo", H, qd, 0)
             ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_o, B * H, ops.ptr(ws.h), ops.ptr(ws.h),
                      ops.ptr(L["ln2"]), ops.ptr(ws.x16), B, H, eps, ops.sp())

@@ -522,12 +522,16 @@ def test_slab_resnorm_and_embed_norm_x16(dev, M, N, S):
                                atol=0, rtol=8e-3)
 
 
-@pytest.mark.parametrize("B,poss,S", [(1, [0], 1), (3, [5, 127, 200], 4), (2, [408, 535], 2)])
-def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S):
-    """Fused prologue (slab input, X16 output) == q3asr_qk_norm_rope_kv followed by q3asr_attn_decode."""
-    from qwen3_asr_mlx_amd import ops
-    nh, nkv, hd, Lmax = 4, 2, 128, 576
+@pytest.mark.parametrize("B,poss,S,Lmax", [(1, [0], 1, 576), (3, [5, 127, 200], 4, 576), (2, [408, 535], 2, 576),
+                                              (5, [255, 256, 511, 512, 1900], 3, 2048), (40, None, 2, 1920)])
+def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
+    """Fused prologue (slab input, X16 output, 512-token chunks merged by the last workgroup to arrive) ==
+    q3asr_qk_norm_rope_kv followed by q3asr_attn_decode; the workspace is left ready for the next launch."""
+    from qwen3_asr_mlx_amd import _lib, ops
+    nh, nkv, hd = 4, 2, 128
     qkvd = (nh + 2 * nkv) * hd
+    if poss is None:
+        poss = [(37 * j * j + 11) % Lmax for j in range(B)]
     parts = rnd((S, B, qkvd), dev, 140, 1.0, torch.float32)
     qn, kn = rnd((hd,), dev, 141) + 1, rnd((hd,), dev, 142) + 1
     inv = (1e6 ** (-torch.arange(64, dtype=torch.float32) / 64)).to(dev)
@@ -541,14 +545,53 @@ def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S):
     ref = torch.zeros((B, nh * hd), dtype=torch.bfloat16, device=dev)
     ops.call("q3asr_attn_decode", ops.ptr(q), ops.ptr(kc1), ops.ptr(vc1), ops.ptr(pos), ops.ptr(ref), B, nh, nkv, hd, Lmax,
              hd ** -0.5, ops.sp())
-    kc2, vc2 = kc0.clone(), vc0.clone()
     MT = ops.mt_of(B)
-    o16 = torch.zeros((nh * hd // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
-    ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
-             ops.ptr(kc2), ops.ptr(vc2), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.sp())
-    assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
-    # same maths; the partial-merge grouping differs (4 tokens per group per sweep instead of 2)
-    torch.testing.assert_close(ops.from_x16(o16, B).float(), ref.float(), atol=1e-2, rtol=8e-3)
+    nbytes = _lib.load().q3asr_attn_decode_fused_workspace(B, nkv, Lmax)
+    assert nbytes == 4 * (B * nkv * ((Lmax + 511) // 512) * 260 + B * nkv)
+    wsp = torch.zeros((nbytes // 4,), dtype=torch.float32, device=dev)
+    outs = []
+    for rep in range(3):                                       # same workspace, back to back
+        kc2, vc2 = kc0.clone(), vc0.clone()
+        o16 = torch.zeros((nh * hd // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
+                 ops.ptr(kc2), ops.ptr(vc2), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
+        assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+        outs.append(ops.from_x16(o16, B))
+        assert int(wsp.view(torch.int32)[-B * nkv:].abs().sum()) == 0            # arrival counters back at zero
+    # same maths; the partial-merge grouping differs (4 tokens per group per sweep instead of 2, chunk merge)
+    torch.testing.assert_close(outs[0].float(), ref.float(), atol=1e-2, rtol=8e-3)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])      # arrival order does not matter
+
+
+def test_attn_decode_fused_is_independent_of_batch_and_capacity(dev):
+    """A sequence's attention output is bit-identical whatever batch it sits in and whatever the cache capacity
+    (chunks are absolute 512-token ranges merged in chunk order)."""
+    from qwen3_asr_mlx_amd import _lib, ops
+    nh, nkv, hd, S = 4, 2, 128, 2
+    qkvd = (nh + 2 * nkv) * hd
+    qn, kn = rnd((hd,), dev, 141) + 1, rnd((hd,), dev, 142) + 1
+    inv = (1e6 ** (-torch.arange(64, dtype=torch.float32) / 64)).to(dev)
+
+    def run(parts, kc, vc, poss, Lmax):
+        B = len(poss)
+        pos = torch.tensor(poss, dtype=torch.int32, device=dev)
+        wsp = torch.zeros((_lib.load().q3asr_attn_decode_fused_workspace(B, nkv, Lmax) // 4,), dtype=torch.float32, device=dev)
+        o16 = torch.zeros((nh * hd // 32, ops.mt_of(B), 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
+                 ops.ptr(kc), ops.ptr(vc), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
+        return ops.from_x16(o16, B)
+
+    B, Lmax = 20, 1024
+    poss = [700, 3, 256, 999, 511] * 4
+    parts = rnd((S, B, qkvd), dev, 160, 1.0, torch.float32)
+    kc, vc = rnd((B, nkv, Lmax, hd), dev, 161), rnd((B, nkv, Lmax, hd), dev, 162)
+    full = run(parts, kc.clone(), vc.clone(), poss, Lmax)
+    for j in (0, 3, 4):
+        big = torch.zeros((1, nkv, 2048, hd), dtype=torch.bfloat16, device=dev)
+        bigv = torch.zeros_like(big)
+        big[:, :, :Lmax], bigv[:, :, :Lmax] = kc[j:j + 1], vc[j:j + 1]
+        one = run(parts[:, j:j + 1].contiguous(), big, bigv, [poss[j]], 2048)
+        assert torch.equal(one[0], full[j])
 
 
 # ----------------------------------------------------------------------------- fp8 weights (BASELINE.json configs[4])
