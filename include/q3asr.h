@@ -117,7 +117,7 @@ int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_out, const v
                          float eps, void* stream);
 /* decode attention with decoder.py:144-156 (QK-RMSNorm, RoPE, cache append) fused into its prologue;
  * input: the qkv projection as n_slabs fp32 slabs [n_slabs][B][ld]; output att in X16 layout.
- * The cache is processed in 512-token chunks, one workgroup each; sequences longer than a chunk are merged
+ * The cache is processed in 1024-token chunks, one workgroup each; sequences longer than a chunk are merged
  * through `workspace` (q3asr_attn_decode_fused_workspace(B, nkv, Lmax) bytes, zero-filled once by the caller,
  * left zeroed/ready by every launch; launches sharing a workspace must be ordered on one stream). */
 int64_t q3asr_attn_decode_fused_workspace(int B, int nkv, int Lmax);

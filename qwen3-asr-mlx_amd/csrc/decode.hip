@@ -385,7 +385,7 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_o
 // their sum is rounded to bf16 (the projection's output dtype).  The attention output (the o
 // projection's operand) is written in X16 layout.
 //
-// Workgroup (kv head, sequence, 512-token chunk of the cache).  Waves 0,1 normalise/rotate the two query
+// Workgroup (kv head, sequence, group of 1024-token chunks of the cache).  Waves 0,1 normalise/rotate the two query
 // heads; in the chunk that holds the new token waves 2,3 do the same for k and pass v through, and the new
 // k/v go to the cache AND to LDS (the token attends to itself without a global round trip).  A chunk is
 // swept in 128-token batches through a register double buffer (2 x 64 KiB in flight, the first batch issued
@@ -396,7 +396,7 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_o
 // Chunks past the sequence's length exit at once: the grid is sized for the cache capacity because the
 // launch is captured in a graph while positions advance.
 // ---------------------------------------------------------------------------
-#define ADF_CHUNK 512
+#define ADF_CHUNK 1024
 #define ADF_PART (2 * 130)            // floats per (sequence, kv head, chunk): per head 128 numerators, max, sum
 
 __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
 static int adf_chunks_per_wg(int pairs, int nc) {
     static const int forced = [] { const char* e = getenv("Q3ASR_ATTN_CHUNKS_PER_WG"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced < nc ? forced : nc;
-    const float fixed_us = 8.f, chunk_us = 12.f, merge_us = 5.f;
+    const float fixed_us = 8.f, chunk_us = 24.f, merge_us = 5.f;
     int best = nc;
     float best_cost = 1e30f;
     for (int G = nc; G >= 1; --G) {

@@ -523,9 +523,9 @@ def test_slab_resnorm_and_embed_norm_x16(dev, M, N, S):
 
 
 @pytest.mark.parametrize("B,poss,S,Lmax", [(1, [0], 1, 576), (3, [5, 127, 200], 4, 576), (2, [408, 535], 2, 576),
-                                              (5, [255, 256, 511, 512, 1900], 3, 2048), (40, None, 2, 1920)])
+                                              (5, [255, 1023, 1024, 2047, 2900], 3, 3072), (40, None, 2, 1920)])
 def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
-    """Fused prologue (slab input, X16 output, 512-token chunks merged by the last workgroup to arrive) ==
+    """Fused prologue (slab input, X16 output, 1024-token chunks merged by the last workgroup to arrive) ==
     q3asr_qk_norm_rope_kv followed by q3asr_attn_decode; the workspace is left ready for the next launch."""
     from qwen3_asr_mlx_amd import _lib, ops
     nh, nkv, hd = 4, 2, 128
@@ -547,7 +547,7 @@ def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
              hd ** -0.5, ops.sp())
     MT = ops.mt_of(B)
     nbytes = _lib.load().q3asr_attn_decode_fused_workspace(B, nkv, Lmax)
-    assert nbytes == 4 * (B * nkv * ((Lmax + 511) // 512) * 260 + B * nkv)
+    assert nbytes == 4 * (B * nkv * ((Lmax + 1023) // 1024) * 260 + B * nkv)
     wsp = torch.zeros((nbytes // 4,), dtype=torch.float32, device=dev)
     outs = []
     for rep in range(3):                                       # same workspace, back to back
@@ -565,7 +565,7 @@ def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
 
 def test_attn_decode_fused_is_independent_of_batch_and_capacity(dev):
     """A sequence's attention output is bit-identical whatever batch it sits in and whatever the cache capacity
-    (chunks are absolute 512-token ranges merged in chunk order)."""
+    (chunks are absolute 1024-token ranges merged in chunk order)."""
     from qwen3_asr_mlx_amd import _lib, ops
     nh, nkv, hd, S = 4, 2, 128, 2
     qkvd = (nh + 2 * nkv) * hd
@@ -581,16 +581,16 @@ def test_attn_decode_fused_is_independent_of_batch_and_capacity(dev):
                  ops.ptr(kc), ops.ptr(vc), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
         return ops.from_x16(o16, B)
 
-    B, Lmax = 20, 1024
-    poss = [700, 3, 256, 999, 511] * 4
+    B, Lmax = 20, 2560
+    poss = [700, 3, 1024, 2400, 1023] * 4
     parts = rnd((S, B, qkvd), dev, 160, 1.0, torch.float32)
     kc, vc = rnd((B, nkv, Lmax, hd), dev, 161), rnd((B, nkv, Lmax, hd), dev, 162)
     full = run(parts, kc.clone(), vc.clone(), poss, Lmax)
     for j in (0, 3, 4):
-        big = torch.zeros((1, nkv, 2048, hd), dtype=torch.bfloat16, device=dev)
+        big = torch.zeros((1, nkv, 4096, hd), dtype=torch.bfloat16, device=dev)
         bigv = torch.zeros_like(big)
         big[:, :, :Lmax], bigv[:, :, :Lmax] = kc[j:j + 1], vc[j:j + 1]
-        one = run(parts[:, j:j + 1].contiguous(), big, bigv, [poss[j]], 2048)
+        one = run(parts[:, j:j + 1].contiguous(), big, bigv, [poss[j]], 4096)
         assert torch.equal(one[0], full[j])
 
 
