@@ -57,6 +57,9 @@ int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, int Cin, con
 int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
                     const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
                     void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream);
+/* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 128 = 128x128 tile, 256 = 256x256 register-staged,
+ * 8 = 256x256 8-phase LDS-DMA pipeline where its preconditions hold).  All kernels give bit-identical results. */
+int q3asr_gemm_force_kernel(int mode);
 
 /* ---- nn.LayerNorm (encoder.py:112,117,319): x fp32 [M][D] -> y bf16 [M][D] ------------------ */
 int q3asr_layernorm_f32_bf16(const float* x, const float* w, const float* b, void* y, int M, int D, float eps,

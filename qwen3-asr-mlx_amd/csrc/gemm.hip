@@ -35,7 +35,9 @@ struct GemmParams {
     const int* row_map;      // optional destination row per m (<0: skip)
 };
 
-__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+// 128-byte rows: two rows make one 256-byte bank row, so the XOR uses row >> 1 and the row parity supplies the 4th bit:
+// the 16 lanes of a ds_read_b128 group (rows base..base+15, one k slot) land on 16 distinct 16-byte columns.
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 // Epilogue shared by both GEMM kernels.  A lane holds, for accumulator tile (j, i): output row
 // m = m_base + 16 i + li and the 4 consecutive columns n = n_base + 16 j + 4 g + r.
@@ -379,13 +381,205 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     gemm_epilogue<8>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, wn, g, li);
 }
 
+// ---------------------------------------------------------------------------
+// 256x256x64 tile, 8 phases per pair of K tiles: the deep-pipelined variant for plain GEMMs (K % 128 == 0).
+//
+// 8 waves = 2 (M) x 4 (N), each 128 x 64 of the output = 4 quadrants of 4 x 2 MFMA tiles.  A K tile is staged as four
+// 16 KiB half-tiles in the order S = B0, A0, B1, A1 (B* = weight rows of the n-half of every wave column, A* = activation
+// rows of the m-half of both wave rows), written straight into LDS by global_load_lds_dwordx4 (no staging registers)
+// into a ring of 8 slots (2 K tiles, 128 KiB).  The LDS image of a wave instruction is lane-linear (8 rows x 128 B),
+// so the bank swizzle (k slot ^ (row >> 1) & 7) is applied to the SOURCE address and again on the fragment read.
+//
+// Phase g (4 per K tile):  read the fragments of S[g+1] (8 x ds_read_b128 for an A half, 4 for a B half), issue the
+// DMA of S[g+7] into slot (g+7) & 7 (its previous tenant S[g-1] was last read two phases ago), s_waitcnt vmcnt(10)
+// (S[g+2] has landed, five half-tiles stay in flight across the barriers), barrier, 16 MFMAs of quadrant g & 3, barrier.
+// The two wave rows run one barrier apart, so on every SIMD one wave issues MFMAs while the other reads LDS and
+// issues the DMA.  A buffer is read one phase after the wait that retires it (+ the barrier), never in the same phase.
+// ---------------------------------------------------------------------------
+#define G8_SLOT 16384
+#define G8_BAR()                                   \
+    do {                                           \
+        asm volatile("" ::: "memory");             \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+        asm volatile("" ::: "memory");             \
+    } while (0)
+
+struct G8Ctx {
+    const char* A; const char* W;
+    unsigned offA[2][2], offW[2][2];      // [half][instruction]: byte offset of this lane's 16 bytes at k = 0
+    char* ring;                            // LDS ring base
+    int wave_lds;                          // wave * 1024
+    unsigned rdA, rdB;                     // this lane's fragment read offsets inside a half-tile (kk = 0; kk = 1 is ^ 64)
+    int nk;
+};
+
+// DMA of half-tile S[s]: kind = s & 3 (0 B0, 1 A0, 2 B1, 3 A1), K tile = s >> 2 (clamped: the ring keeps turning past the end)
+template <int KIND, int SLOT>
+__device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile) {
+    const unsigned kb = (unsigned)min(ktile, c.nk - 1) * 128u;
+    constexpr int h = KIND >> 1;
+    const char* base = (KIND & 1) ? c.A : c.W;
+    const unsigned o0 = ((KIND & 1) ? c.offA[h][0] : c.offW[h][0]) + kb;
+    const unsigned o1 = ((KIND & 1) ? c.offA[h][1] : c.offW[h][1]) + kb;
+    char* dst = c.ring + SLOT * G8_SLOT + c.wave_lds;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o0),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o1),
+                                     (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+}
+
+template <int SLOT>
+__device__ __forceinline__ void g8_read_a(const G8Ctx& c, bf16x8 (&af)[4][2]) {
+    const char* b = c.ring + SLOT * G8_SLOT;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        af[ii][0] = *reinterpret_cast<const bf16x8*>(b + (c.rdA + ii * 2048));
+        af[ii][1] = *reinterpret_cast<const bf16x8*>(b + ((c.rdA + ii * 2048) ^ 64u));
+    }
+}
+template <int SLOT>
+__device__ __forceinline__ void g8_read_b(const G8Ctx& c, bf16x8 (&bf)[2][2]) {
+    const char* b = c.ring + SLOT * G8_SLOT;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        bf[jj][0] = *reinterpret_cast<const bf16x8*>(b + (c.rdB + jj * 2048));
+        bf[jj][1] = *reinterpret_cast<const bf16x8*>(b + ((c.rdB + jj * 2048) ^ 64u));
+    }
+}
+template <int MH, int NH>
+__device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][8], const bf16x8 (&af)[4][2], const bf16x8 (&bf)[2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+                acc[NH * 2 + jj][MH * 4 + ii] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jj][kk], af[ii][kk], acc[NH * 2 + jj][MH * 4 + ii], 0, 0, 0);
+}
+
+// One phase.  PH = g & 7; `tile` = K tile whose half-tile S[g+7] is issued ((g + 7) >> 2).
+// b0cur: B0 fragments of the K tile being computed; b0nxt: filled in phase 3 (mod 4) for the next K tile.
+template <int PH>
+__device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, f32x4 (&acc)[4][8], bf16x8 (&af)[4][2],
+                                         bf16x8 (&b1)[2][2], bf16x8 (&b0cur)[2][2], bf16x8 (&b0nxt)[2][2]) {
+    constexpr int RS = (PH + 1) & 7, RK = (PH + 1) & 3;          // slot / kind read in this phase
+    if constexpr (RK == 1 || RK == 3) g8_read_a<RS>(c, af);
+    else if constexpr (RK == 2) g8_read_b<RS>(c, b1);
+    else g8_read_b<RS>(c, b0nxt);
+    g8_issue<(PH + 7) & 3, (PH + 7) & 7>(c, issue_tile);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    G8_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr ((PH & 3) == 0) g8_mfma<0, 0>(acc, af, b0cur);
+    else if constexpr ((PH & 3) == 1) g8_mfma<0, 1>(acc, af, b1);
+    else if constexpr ((PH & 3) == 2) g8_mfma<1, 1>(acc, af, b1);
+    else g8_mfma<1, 0>(acc, af, b0cur);
+    __builtin_amdgcn_s_setprio(0);
+    G8_BAR();
+}
+
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem8[];          // the only LDS object: 8 ring slots x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + G2_T - 1) / G2_T, tiles_m = (p.M + G2_T - 1) / G2_T;
+    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    const int group = GROUP_M * tiles_n;
+    const int first_m = (t / group) * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (int)(t % group) % gm;
+    const int tn = (int)(t % group) / gm;
+    const int m0 = tm * G2_T, n0 = tn * G2_T;
+    const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, li = lane & 15;
+
+    G8Ctx c;
+    c.A = reinterpret_cast<const char*>(p.A);
+    c.W = reinterpret_cast<const char*>(p.W);
+    c.ring = smem8;
+    c.wave_lds = wave * 1024;
+    c.nk = p.K / BK;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = 8 * (q * 8 + wave) + (lane >> 3);                // row of the half-tile image this lane fills
+            const int slot = (lane & 7) ^ ((r >> 1) & 7);                   // k slot whose bytes belong at that position
+            const int rowA = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
+            const int rowW = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
+            c.offA[h][q] = (unsigned)(((long)rowA * p.lda + 8 * slot) * 2);
+            c.offW[h][q] = (unsigned)(((long)rowW * p.ldw + 8 * slot) * 2);
+        }
+    c.rdA = (unsigned)((wr * 64 + li) * 128 + ((g ^ (li >> 1)) << 4));
+    c.rdB = (unsigned)((wc * 32 + li) * 128 + ((g ^ (li >> 1)) << 4));
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], b1[2][2], b0e[2][2], b0o[2][2];
+
+    // ---- prologue: S[0..6] in flight, S[0] (B0 of tile 0) and S[1] landed before the first reads
+    g8_issue<0, 0>(c, 0); g8_issue<1, 1>(c, 0); g8_issue<2, 2>(c, 0); g8_issue<3, 3>(c, 0);
+    g8_issue<0, 4>(c, 1); g8_issue<1, 5>(c, 1); g8_issue<2, 6>(c, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    G8_BAR();
+    g8_read_b<0>(c, b0e);
+    if (wr == 1) G8_BAR();                                                 // the second wave row runs one barrier behind
+
+    const int iters = c.nk >> 1;                                            // two K tiles (8 phases) per trip
+    for (int it = 0; it < iters; ++it) {
+        const int t2 = 2 * it;
+        g8_phase<0>(c, t2 + 1, acc, af, b1, b0e, b0o);                      // S[8it+7]  = A1 of tile 2it+1
+        g8_phase<1>(c, t2 + 2, acc, af, b1, b0e, b0o);                      // S[8it+8]  = B0 of tile 2it+2
+        g8_phase<2>(c, t2 + 2, acc, af, b1, b0e, b0o);
+        g8_phase<3>(c, t2 + 2, acc, af, b1, b0e, b0o);                      // reads B0 of tile 2it+1 into b0o
+        g8_phase<4>(c, t2 + 2, acc, af, b1, b0o, b0e);                      // S[8it+11] = A1 of tile 2it+2
+        g8_phase<5>(c, t2 + 3, acc, af, b1, b0o, b0e);
+        g8_phase<6>(c, t2 + 3, acc, af, b1, b0o, b0e);
+        g8_phase<7>(c, t2 + 3, acc, af, b1, b0o, b0e);                      // reads B0 of tile 2it+2 into b0e
+    }
+    if (wr == 0) G8_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the ring's tail DMAs (clamped re-loads) must land before exit
+    gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
+}
+
+static int g_gemm_mode = -1;                                 // Q3ASR_GEMM or q3asr_gemm_force_kernel
+
+extern "C" int q3asr_gemm_force_kernel(int mode) {
+    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 256 || mode == 8, "gemm_force_kernel: mode %d (0 auto, 128, 256, 8 = 8-phase)", mode);
+    g_gemm_mode = mode;
+    return 0;
+}
+
 static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
     const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
     const bool fast = !conv && p.K % BK == 0 && (long)p.M * p.lda < (1L << 31) && (long)p.N * p.ldw < (1L << 31);
     const unsigned tiles256 = (unsigned)((p.M + G2_T - 1) / G2_T) * (unsigned)((p.N + G2_T - 1) / G2_T);
-    static int mode = -1;                                    // Q3ASR_GEMM=128|256 pins a tile size (A/B runs, tests)
-    if (mode < 0) { const char* e = getenv("Q3ASR_GEMM"); mode = e ? atoi(e) : 0; }
-    if (mode == 256 || (mode != 128 && tiles256 >= 6 * 256)) {       // measured: 1.17-1.2x on >= 6 tiles per CU, slower below
+    if (g_gemm_mode < 0) { const char* e = getenv("Q3ASR_GEMM"); g_gemm_mode = e ? atoi(e) : 0; }
+    const int mode = g_gemm_mode;                            // 0 auto; 128 / 256 / 8 pin a kernel (A/B runs, tests)
+    // Kernel choice (measured on the prefill / encoder shapes, tools/bench_gemm.py): the 8-phase kernel wins wherever its
+    // preconditions hold and the grid fills the chip: one 256^2 tile costs ~2.6 128^2 tiles, one workgroup per CU against
+    // two; its epilogue does not overlap anything, so the erf-GELU epilogue on a short K (encoder fc1) stays on 128^2.
+    const bool can8 = fast && p.K % 128 == 0 && p.K >= 256;
+    const unsigned rounds8 = (tiles256 + 255) / 256, rounds128 = (tiles + 255) / 256;
+    const bool want8 = can8 && 2.6f * rounds8 < 1.0f * rounds128 && !(p.act == 1 && p.K < 2048);
+    const bool big = mode == 256 || (mode != 128 && mode != 8 && tiles256 >= 6 * 256);
+    if ((mode == 8 && can8) || (mode == 0 && want8)) {                          // deep-pipelined 8-phase kernel
+        static bool attr8 = false;
+        if (!attr8) {
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
+            attr8 = true;
+        }
+        hipLaunchKernelGGL(gemm8p_kernel, dim3(tiles256), dim3(512), 8 * G8_SLOT, s, p);
+        return;
+    }
+    if (big) {                                                        // measured: 1.17-1.2x on >= 6 tiles per CU, slower below
         const size_t lds = 2 * 2 * G2_T * 128;
         static bool attr_set = false;
         if (!attr_set) {                                     // 128 KiB of dynamic LDS needs the opt-in (once per process)

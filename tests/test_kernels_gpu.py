@@ -188,6 +188,37 @@ def test_gemm_swiglu(dev):
     torch.testing.assert_close(o.float().cpu(), ref, atol=2e-2, rtol=1.6e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 384), (1000, 768, 1024), (2050, 1280, 2048), (515, 256, 6144)])
+def test_gemm_kernels_agree_bitwise(dev, M, N, K):
+    """The 128x128 kernel, the 256x256 register-staged kernel and the 256x256 8-phase LDS-DMA kernel accumulate every
+    output in the same order (k ascending, one MFMA chain): bit-identical results, plain, fp32-out and through the
+    epilogues (bias+GELU, bf16 residual, SwiGLU), including ragged M edges."""
+    from qwen3_asr_mlx_amd import _lib, ops
+    A = rnd((M, K), dev, 40, 1.0)
+    W = rnd((N, K), dev, 41, 1.0 / math.sqrt(K))
+    bias = rnd((N,), dev, 42, 0.5, torch.float32)
+    hb = rnd((M, N), dev, 43)
+    outs = {}
+    try:
+        for mode in (128, 256, 8):
+            _lib.call("q3asr_gemm_force_kernel", mode)
+            o32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+            ops.gemm(A, W, M, N, K, o32, out_fp32=True)
+            og = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            ops.gemm(A, W, M, N, K, og, bias=bias, act=1)
+            orr = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            ops.gemm(A, W, M, N, K, orr, res=hb, res_kind=2, ldres=N)
+            osw = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev)
+            ops.gemm(A, W, M, N, K, osw, act=2)
+            outs[mode] = (o32, og, orr, osw)
+    finally:
+        _lib.call("q3asr_gemm_force_kernel", 0)
+    torch.testing.assert_close(outs[8][0].cpu(), _gemm_ref(A, W), atol=2e-3, rtol=1e-3)
+    for mode in (256, 8):
+        for a, b in zip(outs[128], outs[mode]):
+            assert torch.equal(a, b), mode
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from qwen3_asr_mlx_amd import ops
     A = rnd((4, 60), dev, 1)
