@@ -413,21 +413,59 @@ struct G8Ctx {
     int wave_lds;                          // wave * 1024
     unsigned rdA, rdB;                     // this lane's fragment read offsets inside a half-tile (kk = 0; kk = 1 is ^ 64)
     int nk;
+    // implicit-GEMM conv (k3 s2 p1): offA holds the image's first pixel index instead; per staged row 2*oh | 2*ow << 16
+    unsigned ahw[2][2];
+    unsigned kslot[2];                     // 8 * (k slot this lane stages), per instruction
+    int Hin, Win, Cin, K;
 };
 
+__device__ __attribute__((aligned(16))) unsigned g8_zero[4];               // source of padding taps and of k >= K
+
 // DMA of half-tile S[s]: kind = s & 3 (0 B0, 1 A0, 2 B1, 3 A1), K tile = s >> 2 (clamped: the ring keeps turning past the end)
-template <int KIND, int SLOT>
+template <int KIND, int SLOT, int CONV>
 __device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile) {
-    const unsigned kb = (unsigned)min(ktile, c.nk - 1) * 128u;
+    const int kt = min(ktile, c.nk - 1);
     constexpr int h = KIND >> 1;
-    const char* base = (KIND & 1) ? c.A : c.W;
-    const unsigned o0 = ((KIND & 1) ? c.offA[h][0] : c.offW[h][0]) + kb;
-    const unsigned o1 = ((KIND & 1) ? c.offA[h][1] : c.offW[h][1]) + kb;
     char* dst = c.ring + SLOT * G8_SLOT + c.wave_lds;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o0),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o1),
-                                     (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+    if constexpr (!CONV) {
+        const unsigned kb = (unsigned)kt * 128u;
+        const char* base = (KIND & 1) ? c.A : c.W;
+        const unsigned o0 = ((KIND & 1) ? c.offA[h][0] : c.offW[h][0]) + kb;
+        const unsigned o1 = ((KIND & 1) ? c.offA[h][1] : c.offW[h][1]) + kb;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o0),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o1),
+                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+    } else if constexpr ((KIND & 1) == 0) {                                 // weights: rows of 9*Cin, zero beyond K
+        const char* zero = reinterpret_cast<const char*>(g8_zero);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = kt * 64 + (int)c.kslot[q];
+            const char* src = k < c.K ? c.W + (c.offW[h][q] + (unsigned)kt * 128u) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + 8192 * q), 16, 0, 0);
+        }
+    } else {                                                                // activations: im2col address per lane
+        // a K tile (64) touches at most two taps (Cin >= 64): tap0 from the tile's first k (scalar), tap0 + 1 past kb
+        const int k0 = kt * 64;
+        const int tap0 = k0 / c.Cin, kb = (tap0 + 1) * c.Cin;
+        const int kh0 = tap0 / 3, kw0 = tap0 - 3 * kh0;
+        const int tap1 = tap0 + 1, kh1 = tap1 / 3, kw1 = tap1 - 3 * kh1;
+        const char* zero = reinterpret_cast<const char*>(g8_zero);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = k0 + (int)c.kslot[q];
+            const bool second = k >= kb;
+            const int ci = k - (second ? kb : kb - c.Cin);
+            const int ih = (int)(c.ahw[h][q] & 0xFFFFu) - 1 + (second ? kh1 : kh0);
+            const int iw = (int)(c.ahw[h][q] >> 16) - 1 + (second ? kw1 : kw0);
+            const bool in = k < c.K && (unsigned)ih < (unsigned)c.Hin && (unsigned)iw < (unsigned)c.Win;
+            const long off = ((long)(c.offA[h][q] + (unsigned)(ih * c.Win + iw)) * c.Cin + ci) * 2;
+            const char* src = in ? c.A + off : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + 8192 * q), 16, 0, 0);
+        }
+    }
 }
 
 template <int SLOT>
@@ -462,14 +500,14 @@ __device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][8], const bf16x8 (&af)[4
 
 // One phase.  PH = g & 7; `tile` = K tile whose half-tile S[g+7] is issued ((g + 7) >> 2).
 // b0cur: B0 fragments of the K tile being computed; b0nxt: filled in phase 3 (mod 4) for the next K tile.
-template <int PH>
+template <int PH, int CONV>
 __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, f32x4 (&acc)[4][8], bf16x8 (&af)[4][2],
                                          bf16x8 (&b1)[2][2], bf16x8 (&b0cur)[2][2], bf16x8 (&b0nxt)[2][2]) {
     constexpr int RS = (PH + 1) & 7, RK = (PH + 1) & 3;          // slot / kind read in this phase
     if constexpr (RK == 1 || RK == 3) g8_read_a<RS>(c, af);
     else if constexpr (RK == 2) g8_read_b<RS>(c, b1);
     else g8_read_b<RS>(c, b0nxt);
-    g8_issue<(PH + 7) & 3, (PH + 7) & 7>(c, issue_tile);
+    g8_issue<(PH + 7) & 3, (PH + 7) & 7, CONV>(c, issue_tile);
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -483,6 +521,7 @@ __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, f32x4 (
     G8_BAR();
 }
 
+template <int CONV>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem8[];          // the only LDS object: 8 ring slots x 16 KiB
     const int tid = threadIdx.x, lane = tid & 63;
@@ -502,7 +541,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     c.W = reinterpret_cast<const char*>(p.W);
     c.ring = smem8;
     c.wave_lds = wave * 1024;
-    c.nk = p.K / BK;
+    c.nk = CONV ? (((p.K + BK - 1) / BK + 1) & ~1) : p.K / BK;              // conv: K padded with zero taps to an even tile count
+    c.Hin = p.Hin; c.Win = p.Win; c.Cin = p.Cin; c.K = p.K;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -511,8 +551,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
             const int slot = (lane & 7) ^ ((r >> 1) & 7);                   // k slot whose bytes belong at that position
             const int rowA = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
             const int rowW = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
-            c.offA[h][q] = (unsigned)(((long)rowA * p.lda + 8 * slot) * 2);
+            c.kslot[q] = 8 * slot;
             c.offW[h][q] = (unsigned)(((long)rowW * p.ldw + 8 * slot) * 2);
+            if constexpr (CONV) {
+                const int hw = p.Hout * p.Wout;
+                const int img = rowA / hw, rem = rowA - img * hw;
+                const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
+                c.offA[h][q] = (unsigned)img * (unsigned)(p.Hin * p.Win);
+                c.ahw[h][q] = (unsigned)(2 * oh) | ((unsigned)(2 * ow) << 16);
+            } else {
+                c.offA[h][q] = (unsigned)(((long)rowA * p.lda + 8 * slot) * 2);
+                c.ahw[h][q] = 0;
+            }
         }
     c.rdA = (unsigned)((wr * 64 + li) * 128 + ((g ^ (li >> 1)) << 4));
     c.rdB = (unsigned)((wc * 32 + li) * 128 + ((g ^ (li >> 1)) << 4));
@@ -525,8 +575,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     bf16x8 af[4][2], b1[2][2], b0e[2][2], b0o[2][2];
 
     // ---- prologue: S[0..6] in flight, S[0] (B0 of tile 0) and S[1] landed before the first reads
-    g8_issue<0, 0>(c, 0); g8_issue<1, 1>(c, 0); g8_issue<2, 2>(c, 0); g8_issue<3, 3>(c, 0);
-    g8_issue<0, 4>(c, 1); g8_issue<1, 5>(c, 1); g8_issue<2, 6>(c, 1);
+    g8_issue<0, 0, CONV>(c, 0); g8_issue<1, 1, CONV>(c, 0); g8_issue<2, 2, CONV>(c, 0); g8_issue<3, 3, CONV>(c, 0);
+    g8_issue<0, 4, CONV>(c, 1); g8_issue<1, 5, CONV>(c, 1); g8_issue<2, 6, CONV>(c, 1);
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     G8_BAR();
     g8_read_b<0>(c, b0e);
@@ -535,14 +585,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     const int iters = c.nk >> 1;                                            // two K tiles (8 phases) per trip
     for (int it = 0; it < iters; ++it) {
         const int t2 = 2 * it;
-        g8_phase<0>(c, t2 + 1, acc, af, b1, b0e, b0o);                      // S[8it+7]  = A1 of tile 2it+1
-        g8_phase<1>(c, t2 + 2, acc, af, b1, b0e, b0o);                      // S[8it+8]  = B0 of tile 2it+2
-        g8_phase<2>(c, t2 + 2, acc, af, b1, b0e, b0o);
-        g8_phase<3>(c, t2 + 2, acc, af, b1, b0e, b0o);                      // reads B0 of tile 2it+1 into b0o
-        g8_phase<4>(c, t2 + 2, acc, af, b1, b0o, b0e);                      // S[8it+11] = A1 of tile 2it+2
-        g8_phase<5>(c, t2 + 3, acc, af, b1, b0o, b0e);
-        g8_phase<6>(c, t2 + 3, acc, af, b1, b0o, b0e);
-        g8_phase<7>(c, t2 + 3, acc, af, b1, b0o, b0e);                      // reads B0 of tile 2it+2 into b0e
+        g8_phase<0, CONV>(c, t2 + 1, acc, af, b1, b0e, b0o);                      // S[8it+7]  = A1 of tile 2it+1
+        g8_phase<1, CONV>(c, t2 + 2, acc, af, b1, b0e, b0o);                      // S[8it+8]  = B0 of tile 2it+2
+        g8_phase<2, CONV>(c, t2 + 2, acc, af, b1, b0e, b0o);
+        g8_phase<3, CONV>(c, t2 + 2, acc, af, b1, b0e, b0o);                      // reads B0 of tile 2it+1 into b0o
+        g8_phase<4, CONV>(c, t2 + 2, acc, af, b1, b0o, b0e);                      // S[8it+11] = A1 of tile 2it+2
+        g8_phase<5, CONV>(c, t2 + 3, acc, af, b1, b0o, b0e);
+        g8_phase<6, CONV>(c, t2 + 3, acc, af, b1, b0o, b0e);
+        g8_phase<7, CONV>(c, t2 + 3, acc, af, b1, b0o, b0e);                      // reads B0 of tile 2it+2 into b0e
     }
     if (wr == 0) G8_BAR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the ring's tail DMAs (clamped re-loads) must land before exit
@@ -570,13 +620,18 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
     const unsigned rounds8 = (tiles256 + 255) / 256, rounds128 = (tiles + 255) / 256;
     const bool want8 = can8 && 2.6f * rounds8 < 1.0f * rounds128 && !(p.act == 1 && p.K < 2048);
     const bool big = mode == 256 || (mode != 128 && mode != 8 && tiles256 >= 6 * 256);
-    if ((mode == 8 && can8) || (mode == 0 && want8)) {                          // deep-pipelined 8-phase kernel
+    const bool can8c = conv && p.Cin >= 64 && p.K >= 256 && (long)p.N * p.ldw < (1L << 31) && p.Hin < 32768 && p.Win < 32768 &&
+                       (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win < (1L << 32);
+    const bool want8c = can8c && tiles256 >= 192;
+    if ((mode == 8 && (can8 || can8c)) || (mode == 0 && (want8 || want8c))) {      // deep-pipelined 8-phase kernel
         static bool attr8 = false;
         if (!attr8) {
-            (void)hipFuncSetAttribute((const void*)gemm8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
             attr8 = true;
         }
-        hipLaunchKernelGGL(gemm8p_kernel, dim3(tiles256), dim3(512), 8 * G8_SLOT, s, p);
+        if (conv) hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), 8 * G8_SLOT, s, p);
+        else hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(tiles256), dim3(512), 8 * G8_SLOT, s, p);
         return;
     }
     if (big) {                                                        // measured: 1.17-1.2x on >= 6 tiles per CU, slower below

@@ -219,6 +219,27 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
             assert torch.equal(a, b), mode
 
 
+def test_gemm_8phase_is_stable_under_load(dev):
+    """Race screen for the 8-phase pipeline (LDS-DMA data is ordered only by counted waits + barriers): 30 back-to-back
+    launches of a chip-filling shape, each compared bit for bit with the 128x128 kernel's result."""
+    from qwen3_asr_mlx_amd import _lib, ops
+    M, N, K = 4096, 4096 + 256, 2048 + 128
+    A = rnd((M, K), dev, 50, 1.0)
+    W = rnd((N, K), dev, 51, 1.0 / math.sqrt(K))
+    try:
+        _lib.call("q3asr_gemm_force_kernel", 128)
+        ref = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, W, M, N, K, ref)
+        _lib.call("q3asr_gemm_force_kernel", 8)
+        outs = [torch.empty((M, N), dtype=torch.bfloat16, device=dev) for _ in range(30)]
+        for o in outs:
+            ops.gemm(A, W, M, N, K, o)
+    finally:
+        _lib.call("q3asr_gemm_force_kernel", 0)
+    bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+    assert not bad, bad
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from qwen3_asr_mlx_amd import ops
     A = rnd((4, 60), dev, 1)
@@ -262,6 +283,29 @@ def test_conv3x3s2_implicit_gemm(dev, imgs, H, W_, C):
     ops.conv3x3s2(x, imgs, H, W_, C, w.reshape(C, 9 * C), C, b, 1, out)
     ref = F.gelu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), b.cpu(), stride=2, padding=1))
     torch.testing.assert_close(out.float().cpu(), bfr(ref.permute(0, 2, 3, 1)), atol=2e-2, rtol=8e-3)
+
+
+@pytest.mark.parametrize("imgs,H,W_,C,Co", [(40, 25, 32, 480, 480), (9, 64, 50, 96, 256), (33, 13, 16, 64, 512)])
+def test_conv3x3s2_kernels_agree_bitwise(dev, imgs, H, W_, C, Co):
+    """The implicit-GEMM conv through the 128x128, 256x256 and 8-phase kernels (im2col addresses generated in the DMA's
+    source address, padding taps and the K tail read from a zero line): identical bits; checked against torch too."""
+    from qwen3_asr_mlx_amd import _lib, ops
+    x = rnd((imgs, H, W_, C), dev, 53)
+    w = rnd((Co, 3, 3, C), dev, 54, 1.0 / math.sqrt(9 * C))
+    b = rnd((Co,), dev, 55, 0.3, torch.float32)
+    Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
+    outs = {}
+    try:
+        for mode in (128, 256, 8):
+            _lib.call("q3asr_gemm_force_kernel", mode)
+            o = torch.empty((imgs, Ho, Wo, Co), dtype=torch.bfloat16, device=dev)
+            ops.conv3x3s2(x, imgs, H, W_, C, w.reshape(Co, 9 * C), Co, b, 1, o)
+            outs[mode] = o
+    finally:
+        _lib.call("q3asr_gemm_force_kernel", 0)
+    ref = F.gelu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), b.cpu(), stride=2, padding=1))
+    torch.testing.assert_close(outs[8].float().cpu(), bfr(ref.permute(0, 2, 3, 1)), atol=2e-2, rtol=8e-3)
+    assert torch.equal(outs[8], outs[128]) and torch.equal(outs[256], outs[128])
 
 
 # ----------------------------------------------------------------------------- attention
