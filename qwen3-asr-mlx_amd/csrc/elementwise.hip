@@ -169,6 +169,72 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(const void* __rest
     dst[lane + 64] = o2;
 }
 
+// Prefill form of the same op on bf16 rows: one workgroup per token, 8 lanes per head with 16-byte accesses, the
+// token's 64 (cos, sin) pairs computed once in LDS and shared by its heads.  Same arithmetic and roundings as the
+// wave-per-head kernel above (bit-identical results).
+__global__ __launch_bounds__(256) void qk_norm_rope_kv_rows_kernel(const bf16* __restrict__ qkv, long ld,
+                                                                   const int* __restrict__ row_b, const int* __restrict__ row_pos,
+                                                                   const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
+                                                                   const float* __restrict__ inv_freq, float eps,
+                                                                   bf16* __restrict__ q_out, bf16* __restrict__ k_cache,
+                                                                   bf16* __restrict__ v_cache, int nh, int nkv, int Lmax) {
+    __shared__ float s_cs[64], s_sn[64];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int b = row_b[m], pos = row_pos[m];
+    if (tid < 64) {
+        float sn, cs;
+        sincosf((float)pos * inv_freq[tid], &sn, &cs);
+        s_cs[tid] = cs;
+        s_sn[tid] = sn;
+    }
+    __syncthreads();
+    const int slots = nh + 2 * nkv, sub = tid & 7;
+    for (int hs = tid >> 3; hs < slots; hs += 32) {
+        const bf16* src = qkv + (long)m * ld + hs * 128 + 8 * sub;
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(src), v2 = *reinterpret_cast<const bf16x8*>(src + 64);
+        if (hs >= nh + nkv) {                               // v: plain append
+            bf16* dst = v_cache + (((long)b * nkv + (hs - nh - nkv)) * Lmax + pos) * 128 + 8 * sub;
+            *reinterpret_cast<bf16x8*>(dst) = v1;
+            *reinterpret_cast<bf16x8*>(dst + 64) = v2;
+            continue;
+        }
+        float x1[8], x2[8], ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x1[e] = bf2f(v1[e]);
+            x2[e] = bf2f(v2[e]);
+        }
+        // the wave-per-head kernel sums x1^2 + x2^2 per lane (pair j, j + 64) and then across lanes with the xor tree
+        // 32, 16, 8, 4, 2, 1 over j: reproduce that order exactly
+        float pj[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pj[e] = x1[e] * x1[e] + x2[e] * x2[e];
+        // lanes j = 8 sub + e: tree level 32/16/8 pairs lanes that differ in sub bits 2/1/0; levels 4/2/1 pair e bits
+#pragma unroll
+        for (int o = 4; o >= 1; o >>= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pj[e] += __shfl_xor(pj[e], o, 64);
+        pj[0] += pj[4]; pj[1] += pj[5]; pj[2] += pj[6]; pj[3] += pj[7];
+        pj[0] += pj[2]; pj[1] += pj[3];
+        ss = (pj[0] + pj[1]) * (1.0f / 128.0f);
+        const float r = rsqrtf(ss + eps);
+        const bf16* nw = (hs < nh ? qn_w : kn_w) + 8 * sub;
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(nw), w2 = *reinterpret_cast<const bf16x8*>(nw + 64);
+        bf16x8 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y1 = round_bf(x1[e] * r * bf2f(w1[e])), y2 = round_bf(x2[e] * r * bf2f(w2[e]));
+            const float cs = s_cs[8 * sub + e], sn = s_sn[8 * sub + e];
+            o1[e] = f2bf(y1 * cs - y2 * sn);
+            o2[e] = f2bf(y1 * sn + y2 * cs);
+        }
+        bf16* dst = (hs < nh ? q_out + (long)m * nh * 128 + hs * 128
+                             : k_cache + (((long)b * nkv + (hs - nh)) * Lmax + pos) * 128) + 8 * sub;
+        *reinterpret_cast<bf16x8*>(dst) = o1;
+        *reinterpret_cast<bf16x8*>(dst + 64) = o2;
+    }
+}
+
 extern "C" int q3asr_qk_norm_rope_kv(const void* qkv, int is_slab, int64_t ld, int n_slabs, int64_t slab_stride,
                                      const int32_t* row_b, const int32_t* row_pos, const void* qn_w, const void* kn_w,
                                      const float* inv_freq, float eps, void* q_out, void* k_cache, void* v_cache, int M,
@@ -183,6 +249,10 @@ extern "C" int q3asr_qk_norm_rope_kv(const void* qkv, int is_slab, int64_t ld, i
         Q3_REQUIRE(n_slabs > 0, "qk_norm_rope_kv: n_slabs=%d", n_slabs);
         hipLaunchKernelGGL(qk_norm_rope_kv_kernel<true>, grid, blk, 0, s, qkv, (long)ld, n_slabs, (long)slab_stride, row_b, row_pos,
                            (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)q_out, (bf16*)k_cache, (bf16*)v_cache, M, nh, nkv, Lmax);
+    } else if (ld % 8 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)q_out & 15) == 0 && ((uintptr_t)k_cache & 15) == 0 &&
+               ((uintptr_t)v_cache & 15) == 0 && ((uintptr_t)qn_w & 15) == 0 && ((uintptr_t)kn_w & 15) == 0) {
+        hipLaunchKernelGGL(qk_norm_rope_kv_rows_kernel, dim3(M), blk, 0, s, (const bf16*)qkv, (long)ld, row_b, row_pos,
+                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)q_out, (bf16*)k_cache, (bf16*)v_cache, nh, nkv, Lmax);
     } else {
         hipLaunchKernelGGL(qk_norm_rope_kv_kernel<false>, grid, blk, 0, s, qkv, (long)ld, 0, 0L, row_b, row_pos,
                            (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)q_out, (bf16*)k_cache, (bf16*)v_cache, M, nh, nkv, Lmax);
