@@ -417,25 +417,30 @@ struct G8Ctx {
     unsigned ahw[2][2];
     unsigned kslot[2];                     // 8 * (k slot this lane stages), per instruction
     int Hin, Win, Cin, K;
+    // plain GEMM (persistent over tiles): offsets are rebuilt from the tile origin at every issue
+    int rr, rw;                            // row of the staged image this lane fills: A half = q*128 + h*64 + rr, W half = q*128 + h*32 + rw
+    unsigned lda2, ldw2;                   // row pitches in bytes
+    int M, N;
 };
 
 __device__ __attribute__((aligned(16))) unsigned g8_zero[4];               // source of padding taps and of k >= K
 
 // DMA of half-tile S[s]: kind = s & 3 (0 B0, 1 A0, 2 B1, 3 A1), K tile = s >> 2 (clamped: the ring keeps turning past the end)
 template <int KIND, int SLOT, int CONV>
-__device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile) {
+__device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile, int tm0, int tn0) {
     const int kt = min(ktile, c.nk - 1);
     constexpr int h = KIND >> 1;
     char* dst = c.ring + SLOT * G8_SLOT + c.wave_lds;
     if constexpr (!CONV) {
-        const unsigned kb = (unsigned)kt * 128u;
-        const char* base = (KIND & 1) ? c.A : c.W;
-        const unsigned o0 = ((KIND & 1) ? c.offA[h][0] : c.offW[h][0]) + kb;
-        const unsigned o1 = ((KIND & 1) ? c.offA[h][1] : c.offW[h][1]) + kb;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o0),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o1),
-                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+        const unsigned kb = (unsigned)kt * 128u + 2u * c.kslot[0];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const char* src;
+            if constexpr (KIND & 1) src = c.A + ((unsigned)min(tm0 + q * 128 + h * 64 + c.rr, c.M - 1) * c.lda2 + kb);
+            else src = c.W + ((unsigned)min(tn0 + q * 128 + h * 32 + c.rw, c.N - 1) * c.ldw2 + kb);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + 8192 * q), 16, 0, 0);
+        }
     } else if constexpr ((KIND & 1) == 0) {                                 // weights: rows of 9*Cin, zero beyond K
         const char* zero = reinterpret_cast<const char*>(g8_zero);
 #pragma unroll
@@ -501,13 +506,13 @@ __device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][8], const bf16x8 (&af)[4
 // One phase.  PH = g & 7; `tile` = K tile whose half-tile S[g+7] is issued ((g + 7) >> 2).
 // b0cur: B0 fragments of the K tile being computed; b0nxt: filled in phase 3 (mod 4) for the next K tile.
 template <int PH, int CONV>
-__device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, f32x4 (&acc)[4][8], bf16x8 (&af)[4][2],
+__device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0, int tn0, f32x4 (&acc)[4][8], bf16x8 (&af)[4][2],
                                          bf16x8 (&b1)[2][2], bf16x8 (&b0cur)[2][2], bf16x8 (&b0nxt)[2][2]) {
     constexpr int RS = (PH + 1) & 7, RK = (PH + 1) & 3;          // slot / kind read in this phase
     if constexpr (RK == 1 || RK == 3) g8_read_a<RS>(c, af);
     else if constexpr (RK == 2) g8_read_b<RS>(c, b1);
     else g8_read_b<RS>(c, b0nxt);
-    g8_issue<(PH + 7) & 3, (PH + 7) & 7, CONV>(c, issue_tile);
+    g8_issue<(PH + 7) & 3, (PH + 7) & 7, CONV>(c, issue_tile, tm0, tn0);
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -521,19 +526,28 @@ __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, f32x4 (
     G8_BAR();
 }
 
+// Plain GEMMs run persistently: gridDim.x workgroups walk the tile list (tile v, v + gridDim.x, ...), and the DMA ring
+// keeps turning across the seam, so the first seven half-tiles of the next output tile are already in flight while the
+// last phases of the current one compute and while the epilogue stores; the wave rows re-align for the epilogue and
+// stagger again after it.  The conv variant takes one tile per workgroup (its per-row im2col state is per tile).
 template <int CONV>
-__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem8[];          // the only LDS object: 8 ring slots x 16 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.N + G2_T - 1) / G2_T, tiles_m = (p.M + G2_T - 1) / G2_T;
-    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
     const int group = GROUP_M * tiles_n;
-    const int first_m = (t / group) * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (int)(t % group) % gm;
-    const int tn = (int)(t % group) / gm;
-    const int m0 = tm * G2_T, n0 = tn * G2_T;
+    auto tile_origin = [&](int v, int& m0, int& n0) {                       // same grouped, XCD-aware order as the other kernels
+        const unsigned t = xcd_remap((unsigned)v, (unsigned)total_tiles);
+        const int first_m = (t / group) * GROUP_M;
+        const int gm = min(tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (int)(t % group) % gm) * G2_T;
+        n0 = ((int)(t % group) / gm) * G2_T;
+    };
+    int v = blockIdx.x, m0, n0, m0n, n0n;
+    tile_origin(v, m0, n0);
+    m0n = m0; n0n = n0;
+    if (v + (int)gridDim.x < total_tiles) tile_origin(v + gridDim.x, m0n, n0n);
     const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, li = lane & 15;
 
     G8Ctx c;
@@ -543,60 +557,76 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p) {
     c.wave_lds = wave * 1024;
     c.nk = CONV ? (((p.K + BK - 1) / BK + 1) & ~1) : p.K / BK;              // conv: K padded with zero taps to an even tile count
     c.Hin = p.Hin; c.Win = p.Win; c.Cin = p.Cin; c.K = p.K;
+    c.M = p.M; c.N = p.N;
+    c.lda2 = (unsigned)(p.lda * 2); c.ldw2 = (unsigned)(p.ldw * 2);
+    {
+        const int rr = 8 * wave + (lane >> 3);                              // q*64 + rr = row of the half-tile image this lane fills
+        c.rr = rr;
+        c.rw = (rr >> 5) * 64 + (rr & 31);
+        const int slot = (lane & 7) ^ ((rr >> 1) & 7);                      // k slot whose bytes belong at that position (same for q = 0, 1)
+        c.kslot[0] = c.kslot[1] = 8 * slot;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int r = 8 * (q * 8 + wave) + (lane >> 3);                // row of the half-tile image this lane fills
-            const int slot = (lane & 7) ^ ((r >> 1) & 7);                   // k slot whose bytes belong at that position
-            const int rowA = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
-            const int rowW = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
-            c.kslot[q] = 8 * slot;
-            c.offW[h][q] = (unsigned)(((long)rowW * p.ldw + 8 * slot) * 2);
+            c.offA[h][q] = c.offW[h][q] = c.ahw[h][q] = 0;
             if constexpr (CONV) {
+                const int r = 64 * q + c.rr;
+                const int rowA = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
+                const int rowW = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
+                c.offW[h][q] = (unsigned)(((long)rowW * p.ldw + c.kslot[q]) * 2);
                 const int hw = p.Hout * p.Wout;
                 const int img = rowA / hw, rem = rowA - img * hw;
                 const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
                 c.offA[h][q] = (unsigned)img * (unsigned)(p.Hin * p.Win);
                 c.ahw[h][q] = (unsigned)(2 * oh) | ((unsigned)(2 * ow) << 16);
-            } else {
-                c.offA[h][q] = (unsigned)(((long)rowA * p.lda + 8 * slot) * 2);
-                c.ahw[h][q] = 0;
             }
         }
     c.rdA = (unsigned)((wr * 64 + li) * 128 + ((g ^ (li >> 1)) << 4));
     c.rdB = (unsigned)((wc * 32 + li) * 128 + ((g ^ (li >> 1)) << 4));
 
     f32x4 acc[4][8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], b1[2][2], b0e[2][2], b0o[2][2];
 
     // ---- prologue: S[0..6] in flight, S[0] (B0 of tile 0) and S[1] landed before the first reads
-    g8_issue<0, 0, CONV>(c, 0); g8_issue<1, 1, CONV>(c, 0); g8_issue<2, 2, CONV>(c, 0); g8_issue<3, 3, CONV>(c, 0);
-    g8_issue<0, 4, CONV>(c, 1); g8_issue<1, 5, CONV>(c, 1); g8_issue<2, 6, CONV>(c, 1);
+    g8_issue<0, 0, CONV>(c, 0, m0, n0); g8_issue<1, 1, CONV>(c, 0, m0, n0); g8_issue<2, 2, CONV>(c, 0, m0, n0);
+    g8_issue<3, 3, CONV>(c, 0, m0, n0); g8_issue<0, 4, CONV>(c, 1, m0, n0); g8_issue<1, 5, CONV>(c, 1, m0, n0);
+    g8_issue<2, 6, CONV>(c, 1, m0, n0);
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     G8_BAR();
     g8_read_b<0>(c, b0e);
-    if (wr == 1) G8_BAR();                                                 // the second wave row runs one barrier behind
 
     const int iters = c.nk >> 1;                                            // two K tiles (8 phases) per trip
-    for (int it = 0; it < iters; ++it) {
-        const int t2 = 2 * it;
-        g8_phase<0, CONV>(c, t2 + 1, acc, af, b1, b0e, b0o);                      // S[8it+7]  = A1 of tile 2it+1
-        g8_phase<1, CONV>(c, t2 + 2, acc, af, b1, b0e, b0o);                      // S[8it+8]  = B0 of tile 2it+2
-        g8_phase<2, CONV>(c, t2 + 2, acc, af, b1, b0e, b0o);
-        g8_phase<3, CONV>(c, t2 + 2, acc, af, b1, b0e, b0o);                      // reads B0 of tile 2it+1 into b0o
-        g8_phase<4, CONV>(c, t2 + 2, acc, af, b1, b0o, b0e);                      // S[8it+11] = A1 of tile 2it+2
-        g8_phase<5, CONV>(c, t2 + 3, acc, af, b1, b0o, b0e);
-        g8_phase<6, CONV>(c, t2 + 3, acc, af, b1, b0o, b0e);
-        g8_phase<7, CONV>(c, t2 + 3, acc, af, b1, b0o, b0e);                      // reads B0 of tile 2it+2 into b0e
+    const int last_it = iters - 1;                                          // the DMA runs 7 half-tiles ahead: the last trip feeds the next tile
+    while (true) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wr == 1) G8_BAR();                                             // the second wave row runs one barrier behind
+        for (int it = 0; it < iters; ++it) {
+            const int t2 = 2 * it;
+            const bool seam = !CONV && it == last_it;                      // uniform: issues beyond this tile's K belong to the next tile
+            const int im0 = seam ? m0n : m0, in0 = seam ? n0n : n0;
+            const int wrap = seam ? c.nk : 0;
+            g8_phase<0, CONV>(c, t2 + 1, m0, n0, acc, af, b1, b0e, b0o);            // S[8it+7]  = A1 of tile 2it+1
+            g8_phase<1, CONV>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // S[8it+8]  = B0 of tile 2it+2
+            g8_phase<2, CONV>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);
+            g8_phase<3, CONV>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // reads B0 of tile 2it+1 into b0o
+            g8_phase<4, CONV>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // S[8it+11] = A1 of tile 2it+2
+            g8_phase<5, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
+            g8_phase<6, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
+            g8_phase<7, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
+        }
+        if (wr == 0) G8_BAR();                                             // re-align the wave rows
+        gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
+        v += gridDim.x;
+        if (CONV || v >= total_tiles) break;                               // uniform
+        m0 = m0n; n0 = n0n;
+        if (v + (int)gridDim.x < total_tiles) tile_origin(v + gridDim.x, m0n, n0n);
     }
-    if (wr == 0) G8_BAR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the ring's tail DMAs (clamped re-loads) must land before exit
-    gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
 }
 
 static int g_gemm_mode = -1;                                 // Q3ASR_GEMM or q3asr_gemm_force_kernel
@@ -630,8 +660,17 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
             attr8 = true;
         }
-        if (conv) hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), 8 * G8_SLOT, s, p);
-        else hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(tiles256), dim3(512), 8 * G8_SLOT, s, p);
+        if (conv) hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), 8 * G8_SLOT, s, p, (int)tiles256);
+        else {
+            // persistent (one workgroup per CU walking the tile list) where tiles are short and the epilogue light:
+            // it hides the dispatch and the pipeline fill of every tile after the first, but its epilogue stores must
+            // drain before the next tile's counted waits can pass (measured: +8 % at K <= 2048, -2..3 % on long-K or
+            // SwiGLU tiles, tools/bench_gemm.py)
+            static const int force = [] { const char* e = getenv("Q3ASR_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
+            const bool persist = force >= 0 ? force != 0 : (p.K <= 2048 && p.act != 2);
+            const unsigned grid = persist && tiles256 > 256u ? 256u : tiles256;
+            hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(grid), dim3(512), 8 * G8_SLOT, s, p, (int)tiles256);
+        }
         return;
     }
     if (big) {                                                        // measured: 1.17-1.2x on >= 6 tiles per CU, slower below

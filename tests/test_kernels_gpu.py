@@ -188,7 +188,8 @@ def test_gemm_swiglu(dev):
     torch.testing.assert_close(o.float().cpu(), ref, atol=2e-2, rtol=1.6e-2)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 384), (1000, 768, 1024), (2050, 1280, 2048), (515, 256, 6144)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 384), (1000, 768, 1024), (2050, 1280, 2048), (515, 256, 6144),
+                                   (4396, 4096, 1024)])           # 288 tiles: the 8-phase kernel walks two tiles per workgroup
 def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     """The 128x128 kernel, the 256x256 register-staged kernel and the 256x256 8-phase LDS-DMA kernel accumulate every
     output in the same order (k ascending, one MFMA chain): bit-identical results, plain, fp32-out and through the
