@@ -112,6 +112,15 @@ int q3asr_slab_swiglu(const float* slab, int n_slabs, int64_t slab_stride, void*
 int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, const float* w_scale, int N, int K, int n_splits,
                        int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out,
                        int64_t ldo, void* stream);
+/* The same GEMM with the residual add + RMSNorm that produces its activation operand fused into its prologue, for
+ * M <= 2 (single-stream latency): every workgroup rebuilds x = RMSNorm(bf16(h_in + bf16(sum in_slab)))*norm_w from the
+ * previous GEMM's slabs (arithmetic of q3asr_slab_resnorm_x16, bit-identical) while its first weight tiles are in flight;
+ * workgroup 0 also writes the new residual stream to h_out (must differ from h_in; in_slab must differ from slab).
+ * waves_per_wg must be 4, epi 0 or 2.  Replaces q3asr_slab_resnorm_x16 + q3asr_skinny3_gemm (decoder.py:189-196). */
+int q3asr_skinny3_gemm_norm(const float* in_slab, int in_n_slabs, int64_t in_slab_stride, const void* h_in, void* h_out,
+                            const void* norm_w, float eps, int M, const void* W16, const float* w_scale, int N, int K,
+                            int n_splits, int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab,
+                            void* out, int64_t ldo, void* stream);
 /* h = bf16(h + bf16(sum slabs)); x16 = RMSNorm(h)*w in X16 layout (decoder.py:191-196,189,251) */
 int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
                            const void* w, void* x16, int M, int N, float eps, void* stream);

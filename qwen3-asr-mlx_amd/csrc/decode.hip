@@ -41,16 +41,75 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(unsigned lo, unsigned hi) {
     return r;
 }
 
-template <int MT, int EPI, int RT, bool F8>
+// FUSE (M <= 2, 256 threads): the activation operand is not read from X16 but built by every workgroup for itself from
+// the previous GEMM's split-K slabs -- h = bf16(h + bf16(sum slabs)), x = RMSNorm(h) * w, the arithmetic of
+// slab_resnorm_x16_kernel thread for thread (bit-identical) -- into LDS rows, while the first weight tiles are
+// already in flight.  Saves the residual+norm launch of the dependent chain (decoder.py:189-196 at batch 1); workgroup
+// (0, 0) also writes h to a buffer other than h_in (its neighbours are still reading that).
+struct FuseNorm {
+    const float* slab; int S; long stride;
+    const bf16* h_in; bf16* h_out; const bf16* w; float eps;
+};
+
+__device__ __forceinline__ void fuse_norm_prologue(const FuseNorm& f, int M, int K, bf16* xl, float* hl, float* fred, bool writer) {
+    const int NV = K >> 3, tid = threadIdx.x;
+    for (int m = 0; m < M; ++m) {
+        float q2 = 0.f;
+        for (int v = tid; v < NV; v += 256) {
+            const long c0 = (long)m * K + 8 * v;
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(f.slab + c0), a1 = *reinterpret_cast<const f32x4*>(f.slab + c0 + 4);
+            int s = 1;
+            for (; s + 1 < f.S; s += 2) {                  // two slabs per trip: independent loads in flight
+                const float* p = f.slab + s * f.stride + c0;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p), b1 = *reinterpret_cast<const f32x4*>(p + 4);
+                const f32x4 c0v = *reinterpret_cast<const f32x4*>(p + f.stride), c1v = *reinterpret_cast<const f32x4*>(p + f.stride + 4);
+                a0 += b0; a1 += b1; a0 += c0v; a1 += c1v;
+            }
+            if (s < f.S) {
+                const float* p = f.slab + s * f.stride + c0;
+                a0 += *reinterpret_cast<const f32x4*>(p);
+                a1 += *reinterpret_cast<const f32x4*>(p + 4);
+            }
+            const bf16x8 hi = *reinterpret_cast<const bf16x8*>(f.h_in + c0);
+            bf16x8 ho;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = round_bf(round_bf(e < 4 ? a0[e] : a1[e - 4]) + bf2f(hi[e]));
+                hl[8 * v + e] = t;
+                q2 = fmaf(t, t, q2);
+                ho[e] = f2bf(t);
+            }
+            if (writer) *reinterpret_cast<bf16x8*>(f.h_out + c0) = ho;
+        }
+        q2 = wave_sum(q2);
+        if ((tid & 63) == 0) fred[tid >> 6] = q2;
+        __syncthreads();
+        const float r = rsqrtf((fred[0] + fred[1] + fred[2] + fred[3]) * (1.0f / K) + f.eps);
+        for (int v = tid; v < NV; v += 256) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(f.w + 8 * v);
+            bf16x8 xo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xo[e] = f2bf(hl[8 * v + e] * r * bf2f(wv[e]));
+            *reinterpret_cast<bf16x8*>(xl + (long)m * K + 8 * v) = xo;
+        }
+        __syncthreads();
+    }
+}
+
+template <int MT, int EPI, int RT, bool F8, bool FUSE = false>
 __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X16, const void* __restrict__ Wt, int M,
                                                       int N, int K, int kslice, int wg_ksplit, const float* __restrict__ w_scale,
-                                                      float* __restrict__ slab, bf16* __restrict__ out, long ldo) {
-    extern __shared__ f32x4 red[];                          // wg_ksplit: [waves][RT][MT][64]
+                                                      float* __restrict__ slab, bf16* __restrict__ out, long ldo, const FuseNorm fz) {
+    extern __shared__ f32x4 red_raw[];                      // [FUSE: x rows [2][K] bf16 | K floats] wg_ksplit: [waves][RT][MT][64]
+    __shared__ float fred[4];
+    bf16* xl = reinterpret_cast<bf16*>(red_raw);            // row-major: lanes of rows >= M re-read the last row (results unused)
+    float* hl = reinterpret_cast<float*>(reinterpret_cast<char*>(red_raw) + (size_t)K * 4);
+    f32x4* red = FUSE ? reinterpret_cast<f32x4*>(reinterpret_cast<char*>(red_raw) + (size_t)K * 8) : red_raw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int rt0 = (wg_ksplit ? blockIdx.x : blockIdx.x * waves + wave) * RT;
     const int n_tiles = N >> 4;
-    if (rt0 >= n_tiles) return;                             // whole workgroup when wg_ksplit; else no barrier below
+    if (!FUSE && rt0 >= n_tiles) return;                    // whole workgroup when wg_ksplit; else no barrier below
     const int nks = wg_ksplit ? (kslice >> 5) / waves : (kslice >> 5);
     const int ks0 = blockIdx.y * (kslice >> 5) + (wg_ksplit ? wave * nks : 0);
     f32x4 acc[RT][MT];
@@ -59,6 +118,7 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16* xp = X16 + (long)ks0 * MT * 512 + lane * 8;
+    const int xrow = min(lane & 15, M - 1) * K + 8 * (lane >> 4);      // FUSE: this lane's fragment inside the LDS rows
     if (!F8) {
         const bf16* W16 = (const bf16*)Wt;
         const long tile_stride = (long)(K >> 5) * 512;
@@ -82,7 +142,9 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
                 if (ks + i < nks) {
                     bf16x8 xf[MT];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(xp + ((long)(ks + i) * MT + mt) * 512);
+                    for (int mt = 0; mt < MT; ++mt)
+                        xf[mt] = FUSE ? *reinterpret_cast<const bf16x8*>(xl + xrow + (ks0 + ks + i) * 32)
+                                      : *reinterpret_cast<const bf16x8*>(xp + ((long)(ks + i) * MT + mt) * 512);
 #pragma unroll
                     for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -92,6 +154,10 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
             }
         };
         loadw(wA, 0);
+        if constexpr (FUSE) {
+            fuse_norm_prologue(fz, M, K, xl, hl, fred, blockIdx.x == 0 && blockIdx.y == 0);
+            if (rt0 >= n_tiles) return;                     // after the prologue's barriers (wg_ksplit: whole workgroup)
+        }
         for (int ks = 0; ks < nks; ks += 2 * G) {
             if (ks + G < nks) loadw(wB, ks + G);
             compute(wA, ks);
@@ -126,7 +192,8 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
                         bf16x8 xf[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            xf[mt] = *reinterpret_cast<const bf16x8*>(xp + ((long)(2 * (kp + i) + h) * MT + mt) * 512);
+                            xf[mt] = FUSE ? *reinterpret_cast<const bf16x8*>(xl + xrow + (ks0 + 2 * (kp + i) + h) * 32)
+                                          : *reinterpret_cast<const bf16x8*>(xp + ((long)(2 * (kp + i) + h) * MT + mt) * 512);
 #pragma unroll
                         for (int t = 0; t < RT; ++t) {
                             const bf16x8 wf = h == 0 ? fp8x8_to_bf16(w[i][t][0], w[i][t][1]) : fp8x8_to_bf16(w[i][t][2], w[i][t][3]);
@@ -139,6 +206,10 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
             }
         };
         loadw(wA, 0);
+        if constexpr (FUSE) {
+            fuse_norm_prologue(fz, M, K, xl, hl, fred, blockIdx.x == 0 && blockIdx.y == 0);
+            if (rt0 >= n_tiles) return;
+        }
         for (int kp = 0; kp < nkp; kp += 2 * G) {
             if (kp + G < nkp) loadw(wB, kp + G);
             compute(wA, kp);
@@ -208,39 +279,75 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
     }
 }
 
-extern "C" int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, const float* w_scale, int N, int K, int n_splits,
-                                  int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out,
-                                  int64_t ldo, void* stream) {
-    Q3_REQUIRE(X16 && W16, "skinny3_gemm: null pointer");
-    Q3_REQUIRE(M > 0 && M <= 64 && N > 0 && N % 16 == 0, "skinny3_gemm: M=%d must be 1..64, N=%d a multiple of 16", M, N);
-    Q3_REQUIRE(epi >= 0 && epi <= 2 && (waves_per_wg == 1 || waves_per_wg == 2 || waves_per_wg == 4), "skinny3_gemm: bad epi/waves");
-    Q3_REQUIRE(tiles_per_wave == 1 || tiles_per_wave == 2 || tiles_per_wave == 4, "skinny3_gemm: tiles_per_wave=%d", tiles_per_wave);
+static int skinny3_launch(const char* who, const void* X16, const FuseNorm* fuse, int M, const void* W16, const float* w_scale, int N, int K,
+                          int n_splits, int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out,
+                          int64_t ldo, void* stream) {
+    Q3_REQUIRE((X16 || fuse) && W16, "%s: null pointer", who);
+    Q3_REQUIRE(M > 0 && M <= 64 && N > 0 && N % 16 == 0, "%s: M=%d must be 1..64, N=%d a multiple of 16", who, M, N);
+    Q3_REQUIRE(epi >= 0 && epi <= 2 && (waves_per_wg == 1 || waves_per_wg == 2 || waves_per_wg == 4), "%s: bad epi/waves", who);
+    Q3_REQUIRE(tiles_per_wave == 1 || tiles_per_wave == 2 || tiles_per_wave == 4, "%s: tiles_per_wave=%d", who, tiles_per_wave);
     const int kq = w_scale ? 64 : 32;                       // fp8 tiles are addressed in pairs of k steps
-    Q3_REQUIRE(n_splits >= 1 && K % (n_splits * kq) == 0, "skinny3_gemm: K=%d must be a multiple of %d*n_splits (%d)", K, kq, n_splits);
-    if (epi == 0) Q3_REQUIRE(slab, "skinny3_gemm: slab epilogue without workspace");
-    else Q3_REQUIRE(out && n_splits == 1, "skinny3_gemm: direct epilogues need out and n_splits == 1");
-    if (epi == 1) Q3_REQUIRE(ldo % 4 == 0 && ldo >= N, "skinny3_gemm: bad ldo");
-    if (epi == 2) Q3_REQUIRE(tiles_per_wave >= 2 && (N / 16) % tiles_per_wave == 0, "skinny3_gemm: SwiGLU needs whole (gate,up) tile pairs per wave");
+    Q3_REQUIRE(n_splits >= 1 && K % (n_splits * kq) == 0, "%s: K=%d must be a multiple of %d*n_splits (%d)", who, K, kq, n_splits);
+    if (epi == 0) Q3_REQUIRE(slab, "%s: slab epilogue without workspace", who);
+    else Q3_REQUIRE(out && n_splits == 1, "%s: direct epilogues need out and n_splits == 1", who);
+    if (epi == 1) Q3_REQUIRE(ldo % 4 == 0 && ldo >= N, "%s: bad ldo", who);
+    if (epi == 2) Q3_REQUIRE(tiles_per_wave >= 2 && (N / 16) % tiles_per_wave == 0, "%s: SwiGLU needs whole (gate,up) tile pairs per wave", who);
     const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     const int RT = tiles_per_wave;
     const int n_tiles = N / 16;
     const int per_wg = (wg_ksplit ? 1 : waves_per_wg) * RT;
-    if (wg_ksplit) Q3_REQUIRE((K / n_splits) % (kq * waves_per_wg) == 0, "skinny3_gemm: K slice not divisible among the waves");
+    if (wg_ksplit) Q3_REQUIRE((K / n_splits) % (kq * waves_per_wg) == 0, "%s: K slice not divisible among the waves", who);
     dim3 grid((n_tiles + per_wg - 1) / per_wg, n_splits), blk(64 * waves_per_wg);
-    const size_t lds = wg_ksplit ? (size_t)waves_per_wg * RT * MT * 64 * sizeof(f32x4) : 0;
+    size_t lds = wg_ksplit ? (size_t)waves_per_wg * RT * MT * 64 * sizeof(f32x4) : 0;
     hipStream_t s = (hipStream_t)stream;
     const bf16* x = (const bf16*)X16; bf16* o = (bf16*)out;
     const int kslice = K / n_splits;
-#define Q3_L(MT_, EPI_, RT_, F8_) hipLaunchKernelGGL((skinny3_kernel<MT_, EPI_, RT_, F8_>), grid, blk, lds, s, x, W16, M, N, K, kslice, wg_ksplit, w_scale, slab, o, (long)ldo)
+    FuseNorm fz{};
+    if (fuse) {
+        fz = *fuse;
+        Q3_REQUIRE(M <= 2 && waves_per_wg == 4 && epi != 1 && K % 32 == 0, "%s: fused norm needs M <= 2, 4 waves per workgroup, epi 0 or 2", who);
+        Q3_REQUIRE(fz.slab && fz.S >= 1 && fz.h_in && fz.h_out && fz.w && fz.h_in != fz.h_out && fz.slab != slab,
+                   "%s: fused norm needs its own input slabs and distinct h_in / h_out", who);
+        lds += (size_t)K * 8;                               // two bf16 rows + K floats
+        Q3_REQUIRE(lds <= 144 * 1024, "%s: K=%d too large for the fused activation image", who, K);
+    }
+#define Q3_L(MT_, EPI_, RT_, F8_) hipLaunchKernelGGL((skinny3_kernel<MT_, EPI_, RT_, F8_>), grid, blk, lds, s, x, W16, M, N, K, kslice, wg_ksplit, w_scale, slab, o, (long)ldo, fz)
 #define Q3_F(MT_, EPI_, RT_) do { if (w_scale) Q3_L(MT_, EPI_, RT_, true); else Q3_L(MT_, EPI_, RT_, false); } while (0)
 #define Q3_R(MT_, EPI_) do { if (RT == 1) Q3_F(MT_, EPI_, 1); else if (RT == 2) Q3_F(MT_, EPI_, 2); else Q3_F(MT_, EPI_, 4); } while (0)
 #define Q3_M(EPI_) do { if (MT == 1) Q3_R(1, EPI_); else if (MT == 2) Q3_R(2, EPI_); else Q3_R(4, EPI_); } while (0)
-    if (epi == 0) Q3_M(0); else if (epi == 1) Q3_M(1); else Q3_M(2);
+#define Q3_LZ(EPI_, RT_, F8_) do {                                                                                                   \
+        static bool attr = false;                                                                                                    \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)skinny3_kernel<1, EPI_, RT_, F8_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr = true; } \
+        hipLaunchKernelGGL((skinny3_kernel<1, EPI_, RT_, F8_, true>), grid, blk, lds, s, x, W16, M, N, K, kslice, wg_ksplit, w_scale, slab, o, (long)ldo, fz); \
+    } while (0)
+#define Q3_FZ(EPI_, RT_) do { if (w_scale) Q3_LZ(EPI_, RT_, true); else Q3_LZ(EPI_, RT_, false); } while (0)
+#define Q3_RZ(EPI_) do { if (RT == 1) Q3_FZ(EPI_, 1); else if (RT == 2) Q3_FZ(EPI_, 2); else Q3_FZ(EPI_, 4); } while (0)
+    if (fuse) { if (epi == 0) Q3_RZ(0); else Q3_RZ(2); }
+    else if (epi == 0) Q3_M(0); else if (epi == 1) Q3_M(1); else Q3_M(2);
+#undef Q3_RZ
+#undef Q3_FZ
+#undef Q3_LZ
 #undef Q3_M
 #undef Q3_R
 #undef Q3_F
 #undef Q3_L
-    return q3_check_launch("skinny3_gemm");
+    return q3_check_launch(who);
+}
+
+extern "C" int q3asr_skinny3_gemm(const void* X16, int M, const void* W16, const float* w_scale, int N, int K, int n_splits,
+                                  int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab, void* out,
+                                  int64_t ldo, void* stream) {
+    return skinny3_launch("skinny3_gemm", X16, nullptr, M, W16, w_scale, N, K, n_splits, epi, waves_per_wg, tiles_per_wave, wg_ksplit,
+                          slab, out, ldo, stream);
+}
+
+extern "C" int q3asr_skinny3_gemm_norm(const float* in_slab, int in_n_slabs, int64_t in_slab_stride, const void* h_in, void* h_out,
+                                       const void* norm_w, float eps, int M, const void* W16, const float* w_scale, int N, int K,
+                                       int n_splits, int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab,
+                                       void* out, int64_t ldo, void* stream) {
+    FuseNorm f{in_slab, in_n_slabs, (long)in_slab_stride, (const bf16*)h_in, (bf16*)h_out, (const bf16*)norm_w, eps};
+    return skinny3_launch("skinny3_gemm_norm", nullptr, &f, M, W16, w_scale, N, K, n_splits, epi, waves_per_wg, tiles_per_wave,
+                          wg_ksplit, slab, out, ldo, stream);
 }
 
 // ---------------------------------------------------------------------------

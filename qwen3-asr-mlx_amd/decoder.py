@@ -100,6 +100,10 @@ class DecodeWorkspace:
         n_slab = max(self.splits["qkv"] * qkvd, self.splits["o"] * H, self.splits["gu"] * 2 * I, self.splits["down"] * H,
                      self.geo["qkv"][0] * qkvd, self.geo["o"][0] * H, self.geo["down"][0] * H)
         self.slab = torch.empty((n_slab * B,), dtype=torch.float32, device=device)
+        # batch <= 2 runs the residual + RMSNorm inside the consuming GEMM: second slab buffer and residual stream to ping-pong
+        self.fused_norm = B <= 2
+        self.slab2 = torch.empty_like(self.slab) if self.fused_norm else None
+        self.h2 = torch.empty_like(self.h) if self.fused_norm else None
         self.graph = None
         self.graph_key = None
 
@@ -122,6 +126,8 @@ class TextDecoder:
         self._plans: dict = {}
         self._ws: dict = {}
         self.decode_impl = "v3"      # "v1": row-major weights, X through LDS, separate rope/swiglu kernels (kept for A/B)
+        self.fuse_norm = True        # batch <= 2: residual + RMSNorm inside the consuming qkv GEMM (False: separate launches, A/B; tools/ab_batch1.py)
+        self.fuse_norm_gu = True     # ... and inside gate/up too
         self._caches: dict = {}
         self._api_ws = None
 
@@ -320,10 +326,18 @@ class TextDecoder:
         ops.skinny_gemm(ws.x, B, w["embed"], cfg.vocab_size, H, 1, None, ws.logits)
         self.sample_step(ws, ws.logits, sampling)
 
-    def _gemm3(self, ws: DecodeWorkspace, which: str, X16, holder: dict, name: str, N, K, epi, out=None) -> int:
+    def _gemm3(self, ws: DecodeWorkspace, which: str, X16, holder: dict, name: str, N, K, epi, out=None, slab=None) -> int:
         S, waves, rt, ksplit = ws.geo[which]
-        ops.skinny3(X16, ws.B, holder[name + "16"], N, K, epi, S, waves, slab=ws.slab if epi == 0 else None, out=out, rt=rt,
-                    ksplit=ksplit, scale=holder[name + "_s"])
+        ops.skinny3(X16, ws.B, holder[name + "16"], N, K, epi, S, waves, slab=(slab if slab is not None else ws.slab) if epi == 0 else None,
+                    out=out, rt=rt, ksplit=ksplit, scale=holder[name + "_s"])
+        return S
+
+    def _gemm3_norm(self, ws: DecodeWorkspace, which: str, in_slab, s_in, h_in, h_out, norm_w, holder: dict, name: str, N, K, epi,
+                    out=None, slab=None) -> int:
+        """`_gemm3` with residual + RMSNorm of the operand fused in (q3asr_skinny3_gemm_norm: 4 waves per workgroup)."""
+        S, waves, rt, ksplit = ws.geo[which]
+        ops.skinny3_norm(in_slab, s_in, ws.B * K, h_in, h_out, norm_w, self.config.rms_norm_eps, ws.B, holder[name + "16"], N, K, epi, S,
+                         slab=slab if epi == 0 else None, out=out, rt=rt, ksplit=ksplit, scale=holder[name + "_s"])
         return S
 
     def _layers_decode_v3(self, ws: DecodeWorkspace, cache: KVCache, pos) -> None:
@@ -337,6 +351,32 @@ class TextDecoder:
         qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
         eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
         layers = w["layers"]
+        if ws.fused_norm and self.fuse_norm:
+            # batch <= 2: 5 launches per layer.  Slabs: o / down -> ws.slab, read by the fused prologues of gate/up and of the
+            # next layer's qkv, whose own slabs go to ws.slab2 (a kernel must not write the buffer its neighbours still read);
+            # the residual stream ping-pongs between ws.h and ws.h2 for the same reason.
+            h_cur, h_oth, s_d = ws.h, ws.h2, 0
+            for li, L in enumerate(layers):
+                if li == 0:
+                    s_qkv = self._gemm3(ws, "qkv", ws.x16, L, "wqkv", qkvd, H, 0, slab=ws.slab2)
+                else:
+                    s_qkv = self._gemm3_norm(ws, "qkv", ws.slab, s_d, h_cur, h_oth, L["ln1"], L, "wqkv", qkvd, H, 0, slab=ws.slab2)
+                    h_cur, h_oth = h_oth, h_cur
+                ops.call("q3asr_attn_decode_fused", ops.ptr(ws.slab2), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),
+                         ops.ptr(w["inv_freq"]), eps, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(pos), ops.ptr(ws.att16),
+                         B, nh, nkv, hd, Lmax, scale, ops.ptr(cache.attn_ws), ops.sp())
+                s_o = self._gemm3(ws, "o", ws.att16, L, "wo", H, qd, 0)
+                if self.fuse_norm_gu:
+                    self._gemm3_norm(ws, "gu", ws.slab, s_o, h_cur, h_oth, L["ln2"], L, "wgu", 2 * I, H, 2, out=ws.act16)
+                    h_cur, h_oth = h_oth, h_cur
+                else:
+                    ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_o, B * H, ops.ptr(h_cur), ops.ptr(h_cur),
+                             ops.ptr(L["ln2"]), ops.ptr(ws.x16), B, H, eps, ops.sp())
+                    self._gemm3(ws, "gu", ws.x16, L, "wgu", 2 * I, H, 2, out=ws.act16)
+                s_d = self._gemm3(ws, "down", ws.act16, L, "wdown", H, I, 0)
+            ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_d, B * H, ops.ptr(h_cur), ops.ptr(h_cur),
+                     ops.ptr(w["norm"]), ops.ptr(ws.x16), B, H, eps, ops.sp())
+            return
         for li, L in enumerate(layers):
             s_qkv = self._gemm3(ws, "qkv", ws.x16, L, "wqkv", qkvd, H, 0)
             ops.call("q3asr_attn_decode_fused", ops.ptr(ws.slab), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),

@@ -89,6 +89,14 @@ def skinny3(X16, M, W16, N, K, epi, n_splits=1, waves=4, slab=None, out=None, ld
          ldo if ldo is not None else N, sp())
 
 
+def skinny3_norm(in_slab, in_n_slabs, in_stride, h_in, h_out, norm_w, eps, M, W16, N, K, epi, n_splits=1, slab=None, out=None, ldo=None,
+                 rt=None, ksplit=False, scale=None):
+    """skinny3 with the residual add + RMSNorm of its activation operand fused into the prologue (M <= 2, 4 waves)."""
+    rt = rt if rt is not None else (2 if epi == 2 else 1)
+    call("q3asr_skinny3_gemm_norm", ptr(in_slab), in_n_slabs, in_stride, ptr(h_in), ptr(h_out), ptr(norm_w), eps, M, ptr(W16), ptr(scale),
+         N, K, n_splits, epi, 4, rt, 1 if ksplit else 0, ptr(slab), ptr(out), ldo if ldo is not None else N, sp())
+
+
 def pick_splits3(N: int, K: int, waves: int = 4) -> int:
     """Smallest split-K factor that gives >= 256 workgroups (one per CU), K slice >= 128."""
     tiles = (N // 16 + waves - 1) // waves

@@ -575,6 +575,47 @@ def test_skinny3_swiglu_to_x16(dev, M, I, K, waves):
         torch.testing.assert_close(got, bfr(g * torch.sigmoid(g) * u), atol=2e-2, rtol=1.6e-2)
 
 
+@pytest.mark.parametrize("M,N,K,S_in,S,rt,ksplit,epi,fp8", [(1, 4096, 2048, 8, 8, 1, False, 0, False), (2, 1024, 512, 3, 2, 2, False, 0, False),
+                                                              (1, 12288, 2048, 8, 1, 2, True, 2, False), (2, 512, 1024, 6, 1, 4, True, 2, False),
+                                                              (1, 4096, 2048, 6, 4, 1, False, 0, True), (1, 2048, 1024, 1, 1, 2, True, 2, True)])
+def test_skinny3_fused_norm_equals_separate_kernels(dev, M, N, K, S_in, S, rt, ksplit, epi, fp8):
+    """q3asr_skinny3_gemm_norm == q3asr_slab_resnorm_x16 followed by q3asr_skinny3_gemm, bit for bit: the residual
+    stream it writes, and the GEMM output (slabs or SwiGLU activations)."""
+    from qwen3_asr_mlx_amd import ops
+    in_slab = rnd((S_in, M, K), dev, 170, 0.5, torch.float32)
+    h = rnd((M, K), dev, 171)
+    w = rnd((K,), dev, 172) + 1
+    W = rnd((N, K), dev, 173, 1.5 / math.sqrt(K))
+    if fp8:
+        q8, scale, _ = ops.quantize_fp8_rows(W)
+        wt = ops.to_w16f8(q8)
+    else:
+        wt, scale = ops.to_w16(W), None
+    # separate kernels
+    h1 = torch.empty_like(h)
+    x16 = torch.zeros((K // 32, 1, 64, 8), dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_slab_resnorm_x16", ops.ptr(in_slab), S_in, M * K, ops.ptr(h), ops.ptr(h1), ops.ptr(w), ops.ptr(x16), M, K, 1e-6, ops.sp())
+    # fused
+    h2 = torch.zeros_like(h)
+    if epi == 0:
+        ref = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.skinny3(x16, M, wt, N, K, 0, S, 4, slab=ref, rt=rt, ksplit=ksplit, scale=scale)
+        got = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.skinny3_norm(in_slab, S_in, M * K, h, h2, w, 1e-6, M, wt, N, K, 0, S, slab=got, rt=rt, ksplit=ksplit, scale=scale)
+    else:
+        ref = torch.zeros((N // 2 // 32, 1, 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.skinny3(x16, M, wt, N, K, 2, 1, 4, out=ref, rt=rt, ksplit=ksplit, scale=scale)
+        got = torch.zeros_like(ref)
+        ops.skinny3_norm(in_slab, S_in, M * K, h, h2, w, 1e-6, M, wt, N, K, 2, 1, out=got, rt=rt, ksplit=ksplit, scale=scale)
+        ref, got = ops.from_x16(ref, M), ops.from_x16(got, M)
+    assert torch.equal(h2, h1)
+    assert torch.equal(got, ref)
+    with pytest.raises(ValueError):                            # h_in == h_out is refused: neighbours still read h_in
+        ops.skinny3_norm(in_slab, S_in, M * K, h, h, w, 1e-6, M, wt, N, K, epi, S if epi == 0 else 1,
+                         slab=torch.empty((S, M, N), dtype=torch.float32, device=dev) if epi == 0 else None,
+                         out=None if epi == 0 else torch.zeros((N // 2 // 32, 1, 64, 8), dtype=torch.bfloat16, device=dev), rt=rt, ksplit=ksplit, scale=scale)
+
+
 @pytest.mark.parametrize("M,N,S", [(5, 2048, 3), (32, 2048, 8), (33, 512, 1), (2, 4096, 2)])
 def test_slab_resnorm_and_embed_norm_x16(dev, M, N, S):
     import oracle.decoder as od
