@@ -7,12 +7,28 @@ captured into a hipGraph).  bf16 everywhere an MLX op would produce bf16; fp32 a
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from pathlib import Path
 from typing import Optional, Sequence
 
 from . import _lib, ops
 from .config import TextDecoderConfig
 from .tokenizer import ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID
+
+
+# Lanes: independent requests may be in flight on different host threads / HIP streams (two batches interleave well:
+# one decodes, latency-bound, while the other runs its MFMA-bound encoder and prefill).  Weights and read-only plans are
+# shared; everything a launch writes (decode workspace, graph, KV cache, attention workspace, side stream) is per lane.
+_lane = threading.local()
+
+
+def current_lane() -> int:
+    return getattr(_lane, "id", 0)
+
+
+def set_lane(lane: int) -> None:
+    """Bind the calling thread to a lane (default 0).  Call once per worker thread, before its first request."""
+    _lane.id = int(lane)
 
 
 class KVCache:
@@ -267,10 +283,10 @@ class TextDecoder:
 
     # ------------------------------------------------------------------ decode step (hot path)
     def workspace(self, B: int, max_out: int) -> DecodeWorkspace:
-        key = (B, max_out)
+        key = (current_lane(), B, max_out)
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) > 8:
+            if len(self._ws) > 16:
                 self._ws.clear()
             ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device)
         return ws
@@ -278,10 +294,10 @@ class TextDecoder:
     def batch_cache(self, B: int, Lmax: int) -> KVCache:
         """Decoder-owned cache with stable device pointers (so a captured decode graph stays valid
         across calls with the same batch geometry)."""
-        key = (B, Lmax)
+        key = (current_lane(), B, Lmax)
         c = self._caches.get(key)
         if c is None:
-            if len(self._caches) > 2:
+            if len(self._caches) > 4:
                 self._caches.clear()
             c = self._caches[key] = KVCache()
             c.ensure(self.config, B, Lmax, self.device)

@@ -155,9 +155,11 @@ _streams: dict = {}
 
 def _side_stream(dev):
     import torch
-    s = _streams.get(str(dev))
+    from .decoder import current_lane
+    key = (str(dev), current_lane())
+    s = _streams.get(key)
     if s is None:
-        s = _streams[str(dev)] = torch.cuda.Stream(device=dev)
+        s = _streams[key] = torch.cuda.Stream(device=dev)
     return s
 
 

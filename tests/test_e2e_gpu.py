@@ -149,6 +149,41 @@ def test_batch_invariance_and_graph_equals_eager(dev, small):
     assert eager == batched
 
 
+def test_two_lanes_in_flight_equal_sequential(dev, small):
+    """Two host threads, each bound to its own lane (decode workspace, KV cache, graph, streams) over the shared weights,
+    run different batches at the same time: every result equals the one-at-a-time result."""
+    import threading
+    from qwen3_asr_mlx_amd.decoder import set_lane
+    cfg, state, model = small
+    jobs = {1: ([signal("speechlike", 80000, seed=11), signal("noise", 32000, seed=12)], [24, 17]),
+            2: ([signal("speechlike", 48077, seed=13), signal("tone", 16000), signal("noise", 64000, seed=14)], [9, 30, 21])}
+    want = {lane: model.generate_tokens(xs, bud, "English") for lane, (xs, bud) in jobs.items()}
+    got, errs = {}, []
+    gate = threading.Barrier(2)
+
+    def worker(lane):
+        try:
+            set_lane(lane)
+            xs, bud = jobs[lane]
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                gate.wait()
+                outs = [model.generate_tokens(xs, bud, "English") for _ in range(4)]
+                torch.cuda.current_stream().synchronize()
+            got[lane] = outs
+        except Exception as e:                                # noqa: BLE001
+            errs.append(repr(e))
+            gate.abort()
+
+    ths = [threading.Thread(target=worker, args=(lane,)) for lane in jobs]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    for lane in jobs:
+        assert all(o == want[lane] for o in got[lane]), lane
+
+
 def test_sampling_path_runs_and_respects_filters(dev, small):
     cfg, state, model = small
     x = signal("speechlike", 32000)
