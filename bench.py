@@ -110,7 +110,8 @@ def main() -> None:
     ap.add_argument("--ndec", type=int, default=128, help="decoded tokens per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="skip the two-batches-in-flight throughput leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the batches-in-flight throughput leg")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight in the throughput leg (host threads / lanes)")
     ap.add_argument("--weights", choices=("bf16", "fp8"), default="bf16",
                     help="fp8: decoder weights quantised on load (BASELINE.json configs[4]; not the headline config)")
     args = ap.parse_args()
@@ -253,7 +254,7 @@ def main() -> None:
         import threading
         from qwen3_asr_mlx_amd.decoder import set_lane
         n_each, lat2, errs = 3, [], []
-        gate = threading.Barrier(3)
+        gate = threading.Barrier(args.inflight + 1)
 
         def worker(lane):
             try:
@@ -273,7 +274,7 @@ def main() -> None:
                 errs.append(repr(e))
                 gate.abort()
 
-        ths = [threading.Thread(target=worker, args=(lane,)) for lane in (1, 2)]
+        ths = [threading.Thread(target=worker, args=(lane,)) for lane in range(1, args.inflight + 1)]
         for th in ths:
             th.start()
         try:
@@ -287,10 +288,11 @@ def main() -> None:
         for th in ths:
             th.join()
         if dt2 is not None and not errs:
-            line["two_in_flight"] = {"value": 2 * n_each * B * args.clip_seconds / dt2, "unit": "audio-s/wall-s",
-                                     "batches": 2 * n_each, "p50_latency_ms": 1e3 * float(np.median(lat2)),
-                                     "note": "same batch-32 requests, two in flight on two lanes/streams; `value` above is one at a time"}
-            log(f"two batches in flight: RTF {line['two_in_flight']['value']:.0f}x, per-batch latency p50 {line['two_in_flight']['p50_latency_ms']:.0f} ms")
+            key = "two_in_flight" if args.inflight == 2 else f"in_flight_{args.inflight}"
+            line[key] = {"value": args.inflight * n_each * B * args.clip_seconds / dt2, "unit": "audio-s/wall-s",
+                         "batches": args.inflight * n_each, "p50_latency_ms": 1e3 * float(np.median(lat2)),
+                         "note": f"same batch-{B} requests, {args.inflight} in flight on their own lanes/streams; `value` above is one at a time"}
+            log(f"{args.inflight} batches in flight: RTF {line[key]['value']:.0f}x, per-batch latency p50 {line[key]['p50_latency_ms']:.0f} ms")
         else:
             log(f"two-in-flight leg failed: {errs}")
     if world == 1:
