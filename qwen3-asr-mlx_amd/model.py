@@ -73,6 +73,7 @@ class Qwen3ASR:
         self._tokenizer = tokenizer
         self._lock = threading.Lock()
         self.use_graph = True
+        self.lanes = 2              # batches in flight when a request needs more than MAX_BATCH utterances/segments (1: sequential)
 
     @classmethod
     def from_pretrained(cls, model_id_or_path: str | Path, **kwargs) -> "Qwen3ASR":
@@ -217,27 +218,64 @@ class Qwen3ASR:
         """mel -> encoder -> prompt -> generate -> detokenise for a list of (idx, samples, max_tokens)."""
         texts: list[str] = [""] * len(jobs)
         order = sorted(range(len(jobs)), key=lambda j: -len(jobs[j][1]))      # similar lengths share a batch
-        for s in range(0, len(order), self.MAX_BATCH):
-            sel = order[s: s + self.MAX_BATCH]
+        batches = [order[s: s + self.MAX_BATCH] for s in range(0, len(order), self.MAX_BATCH)]
+        seeds = [_next_seed() if temperature else 0 for _ in batches]         # fixed before any thread runs: reproducible
+
+        def run(bi: int) -> None:
+            sel = batches[bi]
             toks = self.generate_tokens([jobs[j][1] for j in sel], [jobs[j][2] for j in sel], lang, temperature, top_p,
-                                        top_k, repetition_penalty, repetition_context_size)
+                                        top_k, repetition_penalty, repetition_context_size, seed=seeds[bi])
             for j, t in zip(sel, toks):
                 texts[j] = self._decode_output(t)
+
+        n_lanes = min(self.lanes, len(batches))
+        if n_lanes <= 1:
+            for bi in range(len(batches)):
+                run(bi)
+            return texts
+        # several batches: keep `lanes` of them in flight (one decodes, latency-bound, while another runs its MFMA-bound
+        # encoder and prefill); each worker thread owns a lane of the decoder and a stream
+        import torch
+        from .decoder import set_lane
+        dev = self._decoder.device
+        nxt, errs, lock = iter(range(len(batches))), [], threading.Lock()
+
+        def worker(lane: int) -> None:
+            try:
+                set_lane(lane)
+                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    while not errs:
+                        with lock:
+                            bi = next(nxt, None)
+                        if bi is None:
+                            break
+                        run(bi)
+                    torch.cuda.current_stream().synchronize()
+            except BaseException as e:                        # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=worker, args=(lane,)) for lane in range(1, n_lanes + 1)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        if errs:
+            raise errs[0]
         return texts
 
     def generate_tokens(self, batch: Sequence[np.ndarray], max_tokens: Sequence[int], lang: str, temperature=0.0,
-                        top_p=1.0, top_k=0, repetition_penalty=1.2, repetition_context_size=100) -> list[list[int]]:
+                        top_p=1.0, top_k=0, repetition_penalty=1.2, repetition_context_size=100, seed=None) -> list[list[int]]:
         """The device part of the hot path for <= MAX_BATCH utterances (steps 5-8 of model.py:330-352)."""
         if self._encoder is None or self._decoder is None:
             raise TypeError("'NoneType' object is not callable")             # use after close(), as the reference
         dev = self._decoder.device
         audio, lens_dev, lens = pack_audio(batch, dev)
         return self.generate_tokens_device(audio, lens_dev, lens, max_tokens, lang, temperature, top_p, top_k,
-                                           repetition_penalty, repetition_context_size)
+                                           repetition_penalty, repetition_context_size, seed)
 
     def generate_tokens_device(self, audio, lens_dev, lens: Sequence[int], max_tokens: Sequence[int], lang: str,
                                temperature=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2,
-                               repetition_context_size=100) -> list[list[int]]:
+                               repetition_context_size=100, seed=None) -> list[list[int]]:
         """Same, with the padded fp32 audio [B][Lmax] and int32 lengths already resident in HBM."""
         if self._encoder is None or self._decoder is None:
             raise TypeError("'NoneType' object is not callable")
@@ -249,8 +287,8 @@ class Qwen3ASR:
         from .tokenizer import build_prompt
         prompts = [build_prompt(n, lang_ids) for n in tok_counts]
         return generate_batch(self._decoder, feats, tok_counts, prompts, list(max_tokens), temperature, top_p, top_k,
-                              repetition_penalty, repetition_context_size, seed=_next_seed() if temperature else 0,
-                              use_graph=self.use_graph)
+                              repetition_penalty, repetition_context_size,
+                              seed=seed if seed is not None else (_next_seed() if temperature else 0), use_graph=self.use_graph)
 
     def _resolve_language(self, language: Optional[str]) -> str:
         if language is None or language.lower() in ("auto", ""):

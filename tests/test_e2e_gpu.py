@@ -184,6 +184,19 @@ def test_two_lanes_in_flight_equal_sequential(dev, small):
         assert all(o == want[lane] for o in got[lane]), lane
 
 
+def test_transcribe_batch_over_max_batch_runs_two_lanes(dev, small):
+    """More utterances than one batch holds: the batches run two at a time on two lanes; texts equal the sequential run."""
+    cfg, state, model = small
+    xs = [signal("speechlike" if i % 3 else "noise", 16000 + 997 * (i % 11), seed=100 + i) for i in range(model.MAX_BATCH + 9)]
+    model.lanes = 1
+    try:
+        seq = [r.text for r in model.transcribe_batch(xs, max_tokens=6)]
+    finally:
+        model.lanes = 2
+    par = [r.text for r in model.transcribe_batch(xs, max_tokens=6)]
+    assert par == seq and len(par) == len(xs)
+
+
 def test_sampling_path_runs_and_respects_filters(dev, small):
     cfg, state, model = small
     x = signal("speechlike", 32000)
