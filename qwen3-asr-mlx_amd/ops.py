@@ -107,13 +107,15 @@ def pick_splits3(N: int, K: int, waves: int = 4) -> int:
     return valid[-1]
 
 
-# Launch geometry of the decode-step GEMMs, measured on MI355X with tools/bench_skinny*.py under rocprofv3
-# (cold weights, batch 32; profiles/r01_skinny_sweep.md).  (N, K) -> (n_splits, waves, tiles/wave, wg_ksplit)
+# Launch geometry of the decode-step GEMMs, chosen INSIDE the captured decode step (tools/tune_decode.py: coordinate
+# descent over (n_splits, waves, tiles/wave, wg_ksplit), graph replays at batch 32, full-size weights): 1843 -> 1784 us
+# per token against the table from isolated launches (profiles/r01_skinny_sweep.md) -- fewer slabs also shorten the
+# kernels that consume them.  (N, K) -> (n_splits, waves, tiles/wave, wg_ksplit)
 _TUNED = {
-    (4096, 2048): (8, 2, 1, False),      # qkv      6.6 us
-    (2048, 2048): (8, 2, 1, False),      # o        5.0 us
-    (2048, 6144): (6, 4, 2, True),       # down     7.9 us
-    (12288, 2048): (1, 4, 2, True),      # gate/up  13.0 us (SwiGLU epilogue, complete sums per workgroup)
+    (4096, 2048): (4, 4, 2, True),       # qkv
+    (2048, 2048): (4, 4, 2, True),       # o
+    (2048, 6144): (8, 4, 1, True),       # down
+    (12288, 2048): (1, 4, 2, True),      # gate/up (SwiGLU epilogue, complete sums per workgroup)
     (151936, 2048): (1, 2, 2, False),    # tied head 117 us (5.3 TB/s)
 }
 
