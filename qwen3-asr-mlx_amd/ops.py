@@ -116,7 +116,7 @@ _TUNED = {
     (2048, 2048): (4, 4, 2, True),       # o
     (2048, 6144): (8, 4, 1, True),       # down
     (12288, 2048): (1, 4, 2, True),      # gate/up (SwiGLU epilogue, complete sums per workgroup)
-    (151936, 2048): (1, 2, 2, False),    # tied head 117 us (5.3 TB/s)
+    (151936, 2048): (1, 4, 2, True),     # tied head (5.3 TB/s)
 }
 
 

@@ -62,29 +62,34 @@ def measure():
     return best * 1e6
 
 
-def candidates(N, K, swiglu):
+def candidates(N, K, swiglu, direct=False):
     out = []
-    for S, waves, rt, ks in itertools.product((1, 2, 3, 4, 6, 8, 12, 16), (2, 4), (1, 2, 4), (False, True)):
-        if K % (32 * S):
+    for S, waves, rt, ks in itertools.product((1, 2, 3, 4, 6, 8, 12, 16), (1, 2, 4), (1, 2, 4), (False, True)):
+        if K % (32 * S) or (waves == 1 and not direct):
             continue
-        if swiglu and (S != 1 or rt < 2 or (N // 16) % rt):
+        if (swiglu or direct) and S != 1:
+            continue
+        if swiglu and (rt < 2 or (N // 16) % rt):
             continue
         if ks and (K // S) % (32 * waves):
             continue
         per_wg = (1 if ks else waves) * rt
         wgs = -(-(N // 16) // per_wg) * S
-        if 192 <= wgs <= 2048 and K // S >= 128:
+        if 192 <= wgs <= (16384 if direct else 2048) and K // S >= 128:
             out.append((S, waves, rt, ks))
     return out
 
 
 base = measure()
 print(f"B={B}: current table {base:.1f} us/token", flush=True)
-shapes = [("qkv", qkvd, H, False), ("o", H, qd, False), ("gu", 2 * I, H, True), ("down", H, I, False)]
-for name, N, K, sw in shapes:
+shapes = [("qkv", qkvd, H, False, False), ("o", H, qd, False, False), ("gu", 2 * I, H, True, False), ("down", H, I, False, False),
+          ("head", t.vocab_size, H, False, True)]
+if len(sys.argv) > 3:
+    shapes = [sh for sh in shapes if sh[0] in sys.argv[3].split(",")]
+for name, N, K, sw, direct in shapes:
     cur = ops._TUNED.get((N, K))
     res = []
-    for c in candidates(N, K, sw):
+    for c in candidates(N, K, sw, direct):
         ops._TUNED[(N, K)] = c
         try:
             res.append((measure(), c))
