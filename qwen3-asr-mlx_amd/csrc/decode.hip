@@ -539,13 +539,29 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
         KK[u] = *reinterpret_cast<const bf16x8*>(Kb + (long)t_ * 128 + 8 * i);                      \
         VV[u] = *reinterpret_cast<const bf16x8*>(Vb + (long)t_ * 128 + 8 * i);                      \
     }
+    // The prologue's own loads go first: a wave's loads return in order, so the slab values must not queue behind the
+    // first 64 KiB of keys and values.
+    const bool pro = wave < 2 || (wave < 4 && owner);
+    const int col = wave < 2 ? (2 * kvh + wave) * 128 : (wave == 2 ? (nh + kvh) * 128 : (nh + nkv + kvh) * 128);
+    const float* src = qkv + (long)b * ld + col;
+    const bf16* nw = wave < 2 ? qn_w : kn_w;
+    float p1[8], p2[8];
+    bf16 nw1 = nw[lane], nw2 = nw[lane + 64];
+    const float freq = inv_freq[lane];
+    if (pro) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                          // 8 slabs: 16 independent loads in flight
+            const bool in = u < n_slabs;
+            p1[u] = in ? src[u * slab_stride + lane] : 0.f;
+            p2[u] = in ? src[u * slab_stride + lane + 64] : 0.f;
+        }
+    }
     Q3_LOAD_BATCH(kA, vA, t0)
-    if (wave < 2 || (wave < 4 && owner)) {
-        const int col = wave < 2 ? (2 * kvh + wave) * 128 : (wave == 2 ? (nh + kvh) * 128 : (nh + nkv + kvh) * 128);
-        const float* src = qkv + (long)b * ld + col;
+    if (pro) {
         float s1 = 0.f, s2 = 0.f;
-        for (int s0 = 0; s0 < n_slabs; s0 += 8) {            // 8 slabs per trip: 16 independent loads in flight
-            float p1[8], p2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += p1[u]; s2 += p2[u]; }          // fixed order s = 0, 1, ...
+        for (int s0 = 8; s0 < n_slabs; s0 += 8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const bool in = s0 + u < n_slabs;
@@ -553,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                 p2[u] = in ? src[(s0 + u) * slab_stride + lane + 64] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { s1 += p1[u]; s2 += p2[u]; }      // fixed order s = 0, 1, ...
+            for (int u = 0; u < 8; ++u) { s1 += p1[u]; s2 += p2[u]; }
         }
         const float x1 = round_bf(s1), x2 = round_bf(s2);
         if (wave == 3) {
@@ -561,12 +577,11 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             s_v[lane] = v1; s_v[lane + 64] = v2;
             Vb[(long)pos * 128 + lane] = v1; Vb[(long)pos * 128 + lane + 64] = v2;
         } else {
-            const bf16* nw = wave < 2 ? qn_w : kn_w;
             const float ss = wave_sum(x1 * x1 + x2 * x2) * (1.0f / 128.0f);
             const float r = rsqrtf(ss + eps);
-            const float y1 = round_bf(x1 * r * bf2f(nw[lane])), y2 = round_bf(x2 * r * bf2f(nw[lane + 64]));
+            const float y1 = round_bf(x1 * r * bf2f(nw1)), y2 = round_bf(x2 * r * bf2f(nw2));
             float sn, cs;
-            sincosf((float)pos * inv_freq[lane], &sn, &cs);
+            sincosf((float)pos * freq, &sn, &cs);
             const float o1 = round_bf(y1 * cs - y2 * sn), o2 = round_bf(y1 * sn + y2 * cs);
             if (wave < 2) { s_q[wave][lane] = o1; s_q[wave][lane + 64] = o2; }
             else {
