@@ -133,6 +133,8 @@ int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_out, const v
  * through `workspace` (q3asr_attn_decode_fused_workspace(B, nkv, Lmax) bytes, zero-filled once by the caller,
  * left zeroed/ready by every launch; launches sharing a workspace must be ordered on one stream). */
 int64_t q3asr_attn_decode_fused_workspace(int B, int nkv, int Lmax);
+/* Test / A-B hook: non-zero selects the lane-group dot-product (VALU) formulation instead of the MFMA one. */
+int q3asr_attn_decode_force_valu(int on);
 int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_slabs, int64_t slab_stride, const void* qn_w,
                             const void* kn_w, const float* inv_freq, float eps, void* k_cache, void* v_cache,
                             const int32_t* pos, void* out16, int B, int nh, int nkv, int head_dim, int Lmax,

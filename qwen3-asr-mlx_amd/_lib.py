@@ -34,6 +34,7 @@ _SIGS = {
     "q3asr_slab_resnorm_x16": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_embed_norm_x16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_attn_decode_fused_workspace": [_i, _i, _i],
+    "q3asr_attn_decode_force_valu": [_i],
     "q3asr_attn_decode_fused": [_vp, _i64, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "q3asr_slab_residual_rmsnorm": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_slab_swiglu": [_vp, _i, _i64, _vp, _i, _i, _vp],

@@ -506,6 +506,11 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_o
 #define ADF_CHUNK 1024
 #define ADF_PART (2 * 130)            // floats per (sequence, kv head, chunk): per head 128 numerators, max, sum
 
+// 256-byte rows of a V tile in LDS: 16-byte chunk ch of row r sits at 256 r + 16 (ch ^ f(r)); conflict-free for the row
+// writes and for the transposing reads (same image as the prefill kernel, attn.hip)
+__device__ __forceinline__ int adm_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <bool MFMA>
 __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
                                                                 const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
                                                                 const float* __restrict__ inv_freq, float eps,
@@ -513,11 +518,14 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                                                                 const int* __restrict__ pos_arr, bf16* __restrict__ out16,
                                                                 int MT, int nh, int nkv, int Lmax, float scale,
                                                                 float* part, int* counters, int nc, int G) {
+    constexpr int NP = MFMA ? 8 : 32;                                 // partials merged per chunk: one per wave / per token slot
     __shared__ float s_q[2][128];
+    __shared__ __attribute__((aligned(16))) bf16 s_qb[2][128];
     __shared__ __attribute__((aligned(16))) bf16 s_k[128], s_v[128];
-    __shared__ float s_m[32][2], s_l[32][2];
-    __shared__ __attribute__((aligned(16))) float s_acc[32][2][128];
+    __shared__ float s_m[NP][2], s_l[NP][2];
+    __shared__ __attribute__((aligned(16))) float s_acc[NP][2][128];
     __shared__ int s_ticket;
+    extern __shared__ __attribute__((aligned(16))) char adm_tiles[];   // MFMA: one 32-key V tile (8 KiB) per wave
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int pos = pos_arr[b];
     const int L = pos + 1, n_active = (L + ADF_CHUNK - 1) / ADF_CHUNK;
@@ -556,7 +564,26 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             p2[u] = in ? src[u * slab_stride + lane + 64] : 0.f;
         }
     }
-    Q3_LOAD_BATCH(kA, vA, t0)
+    if constexpr (!MFMA) { Q3_LOAD_BATCH(kA, vA, t0) }
+    // MFMA path: one register set for a 32-key tile (K as A fragments, V rows on their way to LDS); the next tile's loads
+    // are issued as soon as this tile's K fed the MFMAs and its V sits in LDS.  The first tile is issued here, ahead of
+    // the prologue's arithmetic.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int li = i;
+    bf16x8 kR[2][4];
+    u32x4 vR[8];
+#define ADM_LOAD(KR, VR, TB)                                                                                    \
+    _Pragma("unroll") for (int k4 = 0; k4 < 2; ++k4) {                                                      \
+        const long kr_ = (long)min((TB) + 16 * k4 + li, t_last) * 128 + 8 * g;                              \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) KR[k4][ks] = *reinterpret_cast<const bf16x8*>(Kb + kr_ + 32 * ks); \
+    }                                                                                                       \
+    _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                      \
+        const int c_ = lane + 64 * it;                                                                      \
+        VR[it] = *reinterpret_cast<const u32x4*>(Vb + (long)min((TB) + (c_ >> 4), t_last) * 128 + 8 * (c_ & 15)); \
+        }
+    if constexpr (MFMA) {
+        if (t0 + 32 * wave < min(L, t0 + ADF_CHUNK)) { ADM_LOAD(kR, vR, t0 + 32 * wave) }
+    }
     if (pro) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -583,7 +610,10 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             float sn, cs;
             sincosf((float)pos * freq, &sn, &cs);
             const float o1 = round_bf(y1 * cs - y2 * sn), o2 = round_bf(y1 * sn + y2 * cs);
-            if (wave < 2) { s_q[wave][lane] = o1; s_q[wave][lane + 64] = o2; }
+            if (wave < 2) {
+                s_q[wave][lane] = o1; s_q[wave][lane + 64] = o2;
+                s_qb[wave][lane] = f2bf(o1); s_qb[wave][lane + 64] = f2bf(o2);
+            }
             else {
                 s_k[lane] = f2bf(o1); s_k[lane + 64] = f2bf(o2);
                 Kb[(long)pos * 128 + lane] = f2bf(o1); Kb[(long)pos * 128 + lane + 64] = f2bf(o2);
@@ -593,94 +623,219 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     // The first batch of cached keys/values does not depend on the prologue: it was issued above and is
     // in flight across this barrier.
     __syncthreads();
+    if constexpr (!MFMA) {
     float q0[8], q1[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { q0[e] = s_q[0][8 * i + e]; q1[e] = s_q[1][8 * i + e]; }
-    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
-    float a0[8], a1[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-#define Q3_COMPUTE(KK, VV, T0)                                                                      \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
-        const int t = (T0) + 32 * u + slot;                                                         \
-        bf16x8 kf8 = KK[u], vf8 = VV[u];                                                            \
-        if (t == pos) { /* the new token: from LDS, not from HBM */                                 \
-            kf8 = *reinterpret_cast<const bf16x8*>(s_k + 8 * i);                                    \
-            vf8 = *reinterpret_cast<const bf16x8*>(s_v + 8 * i);                                    \
-        }                                                                                           \
-        float d0 = 0.f, d1 = 0.f;                                                                   \
-        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                             \
-            const float kf = bf2f(kf8[e]);                                                          \
-            d0 = fmaf(q0[e], kf, d0);                                                               \
-            d1 = fmaf(q1[e], kf, d1);                                                               \
-        }                                                                                           \
-        _Pragma("unroll") for (int o = 1; o < 16; o <<= 1) {                                        \
-            d0 += __shfl_xor(d0, o, 64);                                                            \
-            d1 += __shfl_xor(d1, o, 64);                                                            \
-        }                                                                                           \
-        if (t <= pos) {                                                                             \
-            const float s0 = d0 * scale, s1 = d1 * scale;                                           \
-            const float n0 = fmaxf(m0, s0), n1 = fmaxf(m1, s1);                                     \
-            const float al0 = __expf(m0 - n0), al1 = __expf(m1 - n1);                               \
-            const float p0 = __expf(s0 - n0), p1 = __expf(s1 - n1);                                 \
-            l0 = l0 * al0 + p0;                                                                     \
-            l1 = l1 * al1 + p1;                                                                     \
-            m0 = n0;                                                                                \
-            m1 = n1;                                                                                \
-            const float pb0 = round_bf(p0), pb1 = round_bf(p1);                                     \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                         \
-                const float vf = bf2f(vf8[e]);                                                      \
-                a0[e] = fmaf(pb0, vf, a0[e] * al0);                                                 \
-                a1[e] = fmaf(pb1, vf, a1[e] * al1);                                                 \
-            }                                                                                       \
-        }                                                                                           \
-    }
+    #pragma unroll
+        for (int e = 0; e < 8; ++e) { q0[e] = s_q[0][8 * i + e]; q1[e] = s_q[1][8 * i + e]; }
+        float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+        float a0[8], a1[8];
+    #pragma unroll
+        for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+    #define Q3_COMPUTE(KK, VV, T0)                                                                      \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
+            const int t = (T0) + 32 * u + slot;                                                         \
+            bf16x8 kf8 = KK[u], vf8 = VV[u];                                                            \
+            if (t == pos) { /* the new token: from LDS, not from HBM */                                 \
+                kf8 = *reinterpret_cast<const bf16x8*>(s_k + 8 * i);                                    \
+                vf8 = *reinterpret_cast<const bf16x8*>(s_v + 8 * i);                                    \
+            }                                                                                           \
+            float d0 = 0.f, d1 = 0.f;                                                                   \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                             \
+                const float kf = bf2f(kf8[e]);                                                          \
+                d0 = fmaf(q0[e], kf, d0);                                                               \
+                d1 = fmaf(q1[e], kf, d1);                                                               \
+            }                                                                                           \
+            _Pragma("unroll") for (int o = 1; o < 16; o <<= 1) {                                        \
+                d0 += __shfl_xor(d0, o, 64);                                                            \
+                d1 += __shfl_xor(d1, o, 64);                                                            \
+            }                                                                                           \
+            if (t <= pos) {                                                                             \
+                const float s0 = d0 * scale, s1 = d1 * scale;                                           \
+                const float n0 = fmaxf(m0, s0), n1 = fmaxf(m1, s1);                                     \
+                const float al0 = __expf(m0 - n0), al1 = __expf(m1 - n1);                               \
+                const float p0 = __expf(s0 - n0), p1 = __expf(s1 - n1);                                 \
+                l0 = l0 * al0 + p0;                                                                     \
+                l1 = l1 * al1 + p1;                                                                     \
+                m0 = n0;                                                                                \
+                m1 = n1;                                                                                \
+                const float pb0 = round_bf(p0), pb1 = round_bf(p1);                                     \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                         \
+                    const float vf = bf2f(vf8[e]);                                                      \
+                    a0[e] = fmaf(pb0, vf, a0[e] * al0);                                                 \
+                    a1[e] = fmaf(pb1, vf, a1[e] * al1);                                                 \
+                }                                                                                       \
+            }                                                                                           \
+        }
     const int t_end = min(L, c_end * ADF_CHUNK);
-    const int h = (tid >> 7) & 1, d = tid & 127;
-    float* my = part + (((long)b * nkv + kvh) * nc) * ADF_PART;
+        const int h = (tid >> 7) & 1, d = tid & 127;
+        float* my = part + (((long)b * nkv + kvh) * nc) * ADF_PART;
     for (int tt = t0; tt < t_end; tt += 256) {                         // register double buffer: 2 x 64 KiB per workgroup in flight
-        if (tt + 128 < t_end) { Q3_LOAD_BATCH(kB, vB, tt + 128) }
-        Q3_COMPUTE(kA, vA, tt)
-        if (tt + 256 < t_end) { Q3_LOAD_BATCH(kA, vA, tt + 256) }
-        if (tt + 128 < t_end) { Q3_COMPUTE(kB, vB, tt + 128) }
-        if (((tt + 256) % ADF_CHUNK) != 0 && tt + 256 < t_end) continue;
-        // ---- end of a chunk: merge the 32 slots (the next chunk's first batch is already in flight)
-        if (i == 0) { s_m[slot][0] = m0; s_m[slot][1] = m1; s_l[slot][0] = l0; s_l[slot][1] = l1; }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s_acc[slot][0][8 * i + e] = a0[e]; s_acc[slot][1][8 * i + e] = a1[e]; }
-        __syncthreads();
-        if (tid < 256) {
-            float Mx = -INFINITY, num = 0.f, den = 0.f;
-            for (int s = 0; s < 32; ++s) Mx = fmaxf(Mx, s_m[s][h]);
-            for (int s = 0; s < 32; ++s) {
-                const float w = __expf(s_m[s][h] - Mx);
-                num = fmaf(s_acc[s][h][d], w, num);
-                den = fmaf(s_l[s][h], w, den);
-            }
-            if (n_active == 1) {                                      // the whole sequence is this chunk
-                out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(num / den);
-            } else {
-                // Partials travel as device-scope (write-through) atomic stores and loads, so no cache-wide
-                // write-back or invalidate is needed.
-                float* dst = my + (long)(tt / ADF_CHUNK) * ADF_PART + h * 130;
-                __hip_atomic_store(dst + d, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (d == 0) {
-                    __hip_atomic_store(dst + 128, Mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + 129, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tt + 128 < t_end) { Q3_LOAD_BATCH(kB, vB, tt + 128) }
+            Q3_COMPUTE(kA, vA, tt)
+            if (tt + 256 < t_end) { Q3_LOAD_BATCH(kA, vA, tt + 256) }
+            if (tt + 128 < t_end) { Q3_COMPUTE(kB, vB, tt + 128) }
+            if (((tt + 256) % ADF_CHUNK) != 0 && tt + 256 < t_end) continue;
+            // ---- end of a chunk: merge the 32 slots (the next chunk's first batch is already in flight)
+            if (i == 0) { s_m[slot][0] = m0; s_m[slot][1] = m1; s_l[slot][0] = l0; s_l[slot][1] = l1; }
+    #pragma unroll
+            for (int e = 0; e < 8; ++e) { s_acc[slot][0][8 * i + e] = a0[e]; s_acc[slot][1][8 * i + e] = a1[e]; }
+            __syncthreads();
+            if (tid < 256) {
+                float Mx = -INFINITY, num = 0.f, den = 0.f;
+                for (int s = 0; s < 32; ++s) Mx = fmaxf(Mx, s_m[s][h]);
+                for (int s = 0; s < 32; ++s) {
+                    const float w = __expf(s_m[s][h] - Mx);
+                    num = fmaf(s_acc[s][h][d], w, num);
+                    den = fmaf(s_l[s][h], w, den);
+                }
+                if (n_active == 1) {                                      // the whole sequence is this chunk
+                    out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(num / den);
+                } else {
+                    // Partials travel as device-scope (write-through) atomic stores and loads, so no cache-wide
+                    // write-back or invalidate is needed.
+                    float* dst = my + (long)(tt / ADF_CHUNK) * ADF_PART + h * 130;
+                    __hip_atomic_store(dst + d, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d == 0) {
+                        __hip_atomic_store(dst + 128, Mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 129, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
+            if (tt + 256 < t_end) {                                       // another chunk follows: fresh slots
+                __syncthreads();
+                m0 = m1 = -INFINITY;
+                l0 = l1 = 0.f;
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+            }
         }
-        if (tt + 256 < t_end) {                                       // another chunk follows: fresh slots
-            __syncthreads();
-            m0 = m1 = -INFINITY;
-            l0 = l1 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-        }
-    }
 #undef Q3_COMPUTE
+    }
+    if constexpr (MFMA) {
+        // ---- MFMA path: S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16, the two heads of this kv head being two
+        // of the 16 query columns (prefill kernel's formulation, attn.hip).  Wave w owns the 32-key tiles w, w+8, ... of a
+        // chunk: K goes global -> A fragment (lane (li, g): key li, dims 32 ks + 8 g), V through a wave-private LDS tile
+        // and ds_read_b64_tr_b16; the next tile's K/V loads are issued between this tile's QK and its softmax / PV.
+        const int q4 = li >> 2, p4 = li & 3;
+        char* sVw = adm_tiles + wave * 8192;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = bf16x8{};
+            if (li < 2) qf[ks] = *reinterpret_cast<const bf16x8*>(&s_qb[li][32 * ks + 8 * g]);
+        }
+#define ADM_STAGE_QK(KR, VR, TB)                                                                                \
+        {                                                                                                       \
+            if ((TB) + 32 > pos) { /* the tile holding the new token: its K/V come from LDS, not from HBM */    \
+                _Pragma("unroll") for (int k4 = 0; k4 < 2; ++k4)                                                \
+                    if ((TB) + 16 * k4 + li == pos)                                                             \
+                        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) KR[k4][ks] = *reinterpret_cast<const bf16x8*>(s_k + 32 * ks + 8 * g); \
+                _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                              \
+                    const int c_ = lane + 64 * it;                                                              \
+                    if ((TB) + (c_ >> 4) == pos) VR[it] = *reinterpret_cast<const u32x4*>(s_v + 8 * (c_ & 15)); \
+                }                                                                                               \
+            }                                                                                                   \
+            _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                  \
+                const int c_ = lane + 64 * it;                                                                  \
+                *reinterpret_cast<u32x4*>(sVw + adm_off(c_ >> 4, c_ & 15)) = VR[it];                            \
+            }                                                                                                   \
+            _Pragma("unroll") for (int k4 = 0; k4 < 2; ++k4) {                                                  \
+                sc_[k4] = f32x4{0.f, 0.f, 0.f, 0.f};                                                            \
+                _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                \
+                    sc_[k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KR[k4][ks], qf[ks], sc_[k4], 0, 0, 0);    \
+            }                                                                                                   \
+        }
+#define ADM_SOFTMAX_PV(TB)                                                                                      \
+        {                                                                                                       \
+            float tmax_ = -INFINITY;                                                                            \
+            _Pragma("unroll") for (int k4 = 0; k4 < 2; ++k4)                                                    \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
+                    const float v_ = (TB) + 16 * k4 + 4 * g + r <= pos ? sc_[k4][r] * scale : -INFINITY;        \
+                    sc_[k4][r] = v_;                                                                            \
+                    tmax_ = fmaxf(tmax_, v_);                                                                   \
+                }                                                                                               \
+            tmax_ = fmaxf(tmax_, __shfl_xor(tmax_, 16, 64));                                                    \
+            tmax_ = fmaxf(tmax_, __shfl_xor(tmax_, 32, 64));                                                    \
+            const float m_new_ = fmaxf(m_run, tmax_);          /* finite: key TB <= pos is in every tile */      \
+            const float alpha_ = __expf(m_run - m_new_);                                                        \
+            float psum_ = 0.f;                                                                                  \
+            bf16x8 pf_;                                                                                         \
+            _Pragma("unroll") for (int k4 = 0; k4 < 2; ++k4)                                                    \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                 \
+                    const float pv_ = __expf(sc_[k4][r] - m_new_);                                              \
+                    psum_ += pv_;                                                                               \
+                    pf_[k4 * 4 + r] = f2bf(pv_);                                                                \
+                }                                                                                               \
+            l_run = l_run * alpha_ + psum_;                                                                     \
+            m_run = m_new_;                                                                                     \
+            _Pragma("unroll") for (int dt = 0; dt < 8; ++dt) {                                                  \
+                o_[dt] *= alpha_;                                                                               \
+                const int ch_ = 2 * dt + (p4 >> 1), r_lo_ = 4 * g + q4;                                         \
+                const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                      \
+                    (s16x4 __attribute__((address_space(3)))*)(sVw + adm_off(r_lo_, ch_) + 8 * (p4 & 1)));      \
+                const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                      \
+                    (s16x4 __attribute__((address_space(3)))*)(sVw + adm_off(r_lo_ + 16, ch_) + 8 * (p4 & 1))); \
+                union { struct { s16x4 a, b; } h; bf16x8 v; } u_;                                               \
+                u_.h.a = lo_;                                                                                   \
+                u_.h.b = hi_;                                                                                   \
+                o_[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_.v, pf_, o_[dt], 0, 0, 0);                   \
+            }                                                                                                   \
+        }
+        const int t_endm = min(L, c_end * ADF_CHUNK);
+        const int hm = (tid >> 7) & 1, dm = tid & 127;
+        float* mym = part + (((long)b * nkv + kvh) * nc) * ADF_PART;
+        for (int cb = t0; cb < t_endm; cb += ADF_CHUNK) {                 // chunks of this workgroup
+            const int ce = min(t_endm, cb + ADF_CHUNK);
+            f32x4 o_[8];
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) o_[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float m_run = -INFINITY, l_run = 0.f;
+            int tb = cb + 32 * wave;
+            if (cb != t0 && tb < ce) { ADM_LOAD(kR, vR, tb) }             // the first chunk's first tile is already in flight
+            for (; tb < ce; tb += 256) {
+                f32x4 sc_[2];
+                ADM_STAGE_QK(kR, vR, tb)
+                if (tb + 256 < ce) { ADM_LOAD(kR, vR, tb + 256) }
+                ADM_SOFTMAX_PV(tb)
+            }
+            float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+            l_tot += __shfl_xor(l_tot, 32, 64);
+            if (li < 2) {
+                if (g == 0) { s_m[wave][li] = m_run; s_l[wave][li] = l_tot; }
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt)
+                    *reinterpret_cast<f32x4*>(&s_acc[wave][li][16 * dt + 4 * g]) = o_[dt];
+            }
+            __syncthreads();
+            if (tid < 256) {
+                float Mx = -INFINITY, num = 0.f, den = 0.f;
+                for (int w = 0; w < 8; ++w) Mx = fmaxf(Mx, s_m[w][hm]);
+                for (int w = 0; w < 8; ++w) {
+                    const float wgt = __expf(s_m[w][hm] - Mx);             // a wave without tiles holds (-inf, 0, 0): weight 0
+                    num = fmaf(s_acc[w][hm][dm], wgt, num);
+                    den = fmaf(s_l[w][hm], wgt, den);
+                }
+                if (n_active == 1) {
+                    out16[x16_index(b, (2 * kvh + hm) * 128 + dm, MT)] = f2bf(num / den);
+                } else {
+                    float* dst = mym + (long)(cb / ADF_CHUNK) * ADF_PART + hm * 130;
+                    __hip_atomic_store(dst + dm, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (dm == 0) {
+                        __hip_atomic_store(dst + 128, Mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 129, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (ce < t_endm) __syncthreads();                              // the partials are rewritten by the next chunk
+        }
+#undef ADM_SOFTMAX_PV
+#undef ADM_STAGE_QK
+#undef ADM_LOAD
+    }
 #undef Q3_LOAD_BATCH
     if (n_active == 1) return;                                        // uniform
+    const int h = (tid >> 7) & 1, d = tid & 127;
+    float* my = part + (((long)b * nkv + kvh) * nc) * ADF_PART;
     // Each wave waits for its own partial stores to be acknowledged, the barrier collects the waves, and only
     // then is the ticket taken; the last workgroup to arrive merges every chunk of the sequence.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -725,6 +880,9 @@ static int adf_chunks_per_wg(int pairs, int nc) {
     return best;
 }
 
+static int g_attn_force_valu = 0;
+extern "C" int q3asr_attn_decode_force_valu(int on) { g_attn_force_valu = on != 0; return 0; }
+
 extern "C" int64_t q3asr_attn_decode_fused_workspace(int B, int nkv, int Lmax) {
     if (B <= 0 || nkv <= 0 || Lmax <= 0) return 0;
     const int64_t nc = (Lmax + ADF_CHUNK - 1) / ADF_CHUNK;
@@ -743,8 +901,18 @@ extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_
     float* part = (float*)workspace;
     int* counters = (int*)(part + (int64_t)B * nkv * nc * ADF_PART);
     const int G = adf_chunks_per_wg(B * nkv, nc);
-    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
-                       (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
-                       nkv, Lmax, scale, part, counters, nc, G);
+    // MFMA formulation by default; Q3ASR_ATTN=valu keeps the lane-group dot-product kernel (A/B, cross-check in the tests)
+    static const bool valu = [] { const char* e = getenv("Q3ASR_ATTN"); return e && e[0] == 'v'; }();
+    if (valu || g_attn_force_valu) {
+        hipLaunchKernelGGL(attn_decode_fused_kernel<false>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
+                           nkv, Lmax, scale, part, counters, nc, G);
+    } else {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192); attr = true; }
+        hipLaunchKernelGGL(attn_decode_fused_kernel<true>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
+                           nkv, Lmax, scale, part, counters, nc, G);
+    }
     return q3_check_launch("attn_decode_fused");
 }

@@ -153,7 +153,10 @@ def test_decode_split_choice():
     for n, k in ((2048, 2048), (1024, 512), (2048, 1024)):
         s = ops.pick_splits(n, k)
         assert k % (s * 256) == 0
-    assert ops.gemm_geometry(4096, 2048) == (8, 2, 1, False) and ops.gemm_geometry(12288, 2048, swiglu=True) == (1, 4, 2, True)
+    assert ops.gemm_geometry(12288, 2048, swiglu=True) == (1, 4, 2, True)
+    for (n, k), (S, waves, rt, ks) in ops._TUNED.items():           # the measured table obeys the launch preconditions
+        assert k % (32 * S) == 0 and waves in (1, 2, 4) and rt in (1, 2, 4) and (not ks or (k // S) % (32 * waves) == 0)
+        assert (n // 16) % rt == 0
     for n, k in ((1024, 512), (512, 1024), (2048, 512)):             # small-config shapes: generic rule
         S, waves, rt, ks = ops.gemm_geometry(n, k)
         assert k % (32 * S) == 0 and (not ks or (k // S) % (32 * waves) == 0)

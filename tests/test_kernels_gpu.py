@@ -678,9 +678,20 @@ def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
         assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
         outs.append(ops.from_x16(o16, B))
         assert int(wsp.view(torch.int32)[-B * nkv:].abs().sum()) == 0            # arrival counters back at zero
-    # same maths; the partial-merge grouping differs (4 tokens per group per sweep instead of 2, chunk merge)
+    # same maths; the partial-merge grouping differs (32-key MFMA tiles per wave, chunk merge)
     torch.testing.assert_close(outs[0].float(), ref.float(), atol=1e-2, rtol=8e-3)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])      # arrival order does not matter
+    # the lane-group dot-product formulation of the same kernel agrees too
+    try:
+        _lib.call("q3asr_attn_decode_force_valu", 1)
+        kc3, vc3 = kc0.clone(), vc0.clone()
+        o16 = torch.zeros((nh * hd // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
+                 ops.ptr(kc3), ops.ptr(vc3), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
+    finally:
+        _lib.call("q3asr_attn_decode_force_valu", 0)
+    assert torch.equal(kc3, kc1) and torch.equal(vc3, vc1)
+    torch.testing.assert_close(ops.from_x16(o16, B).float(), ref.float(), atol=1e-2, rtol=8e-3)
 
 
 def test_attn_decode_fused_is_independent_of_batch_and_capacity(dev):
