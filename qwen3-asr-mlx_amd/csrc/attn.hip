@@ -74,19 +74,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int n_tiles = CAUSAL ? (qt + 1) : (len + KV_TILE - 1) / KV_TILE;
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        __syncthreads();
-        // stage K and V tile: KV_TILE*CPR chunks each, 256 threads
+    // K and V tile: KV_TILE*CPR 16-byte chunks each, 256 threads; the next tile's chunks are loaded into registers while
+    // the current tile computes (one HBM/L2 round trip per tile would otherwise sit between two barriers)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NCH = KV_TILE * CPR / 256;
+    u32x4 kreg[NCH], vreg[NCH];
+    auto fetch = [&](int kt_) {
 #pragma unroll
-        for (int it = 0; it < KV_TILE * CPR / 256; ++it) {
+        for (int it = 0; it < NCH; ++it) {
             const int c = tid + 256 * it;
             const int row = c / CPR, ch = c - row * CPR;
-            const int key = min(kt * KV_TILE + row, len - 1);
-            const uint4 kv = *reinterpret_cast<const uint4*>(Kb + (long)key * p.kv_row_stride + ch * 8);
-            const uint4 vv = *reinterpret_cast<const uint4*>(Vb + (long)key * p.kv_row_stride + ch * 8);
-            *reinterpret_cast<uint4*>(sK + TileImg<HD>::off(row, ch)) = kv;
-            *reinterpret_cast<uint4*>(sV + TileImg<HD>::off(row, ch)) = vv;
+            const int key = min(kt_ * KV_TILE + row, len - 1);
+            kreg[it] = *reinterpret_cast<const u32x4*>(Kb + (long)key * p.kv_row_stride + ch * 8);
+            vreg[it] = *reinterpret_cast<const u32x4*>(Vb + (long)key * p.kv_row_stride + ch * 8);
         }
+    };
+    fetch(0);
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int c = tid + 256 * it;
+            const int row = c / CPR, ch = c - row * CPR;
+            *reinterpret_cast<u32x4*>(sK + TileImg<HD>::off(row, ch)) = kreg[it];
+            *reinterpret_cast<u32x4*>(sV + TileImg<HD>::off(row, ch)) = vreg[it];
+        }
+        if (kt + 1 < n_tiles) fetch(kt + 1);
         __syncthreads();
 
         // ---- S^T = K Q^T
