@@ -68,6 +68,10 @@ def load():
                     raise Q3AsrError(
                         f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+                # PyTorch-ROCm ships its own libamdhip64; the library must bind to THAT runtime (the one whose device pointers
+                # it is handed), so torch is imported first: loaded the other way round, the two runtimes do not see each
+                # other's device ("no ROCm-capable device is detected" at the first launch).
+                import torch  # noqa: F401
                 lib = C.CDLL(str(LIB_PATH))
                 for name, args in _SIGS.items():
                     fn = getattr(lib, name)
