@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-situ tuning of the decode-step GEMM launch geometry: for each of the four layer GEMMs try (n_splits, waves,
 tiles_per_wave, wg_ksplit) candidates inside the real captured decode step (batch B, full-size random weights) and time
-graph replays.  Coordinate descent, one GEMM at a time.  Usage: tune_decode.py [B] [tokens]"""
+graph replays.  Coordinate descent, one GEMM at a time.  Usage: tune_decode.py [B] [tokens] [names|all] [bf16|fp8]"""
 import itertools
 import sys
 import time
@@ -21,7 +21,8 @@ NT = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 dev = torch.device("cuda:0")
 cfg = ModelConfig()
 state = synth.random_state(cfg, seed=0, device=dev)
-model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
+WDT = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype=WDT)
 del state
 dec = model._decoder
 t = cfg.text_decoder
@@ -64,14 +65,15 @@ def measure():
 
 def candidates(N, K, swiglu, direct=False):
     out = []
+    kq = 64 if WDT == "fp8" else 32
     for S, waves, rt, ks in itertools.product((1, 2, 3, 4, 6, 8, 12, 16), (1, 2, 4), (1, 2, 4), (False, True)):
-        if K % (32 * S) or (waves == 1 and not direct):
+        if K % (kq * S) or (waves == 1 and not direct):
             continue
         if (swiglu or direct) and S != 1:
             continue
         if swiglu and (rt < 2 or (N // 16) % rt):
             continue
-        if ks and (K // S) % (32 * waves):
+        if ks and (K // S) % (kq * waves):
             continue
         per_wg = (1 if ks else waves) * rt
         wgs = -(-(N // 16) // per_wg) * S
@@ -84,7 +86,7 @@ base = measure()
 print(f"B={B}: current table {base:.1f} us/token", flush=True)
 shapes = [("qkv", qkvd, H, False, False), ("o", H, qd, False, False), ("gu", 2 * I, H, True, False), ("down", H, I, False, False),
           ("head", t.vocab_size, H, False, True)]
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[3] != "all":
     shapes = [sh for sh in shapes if sh[0] in sys.argv[3].split(",")]
 for name, N, K, sw, direct in shapes:
     cur = ops._TUNED.get((N, K))
