@@ -233,6 +233,18 @@ def main() -> None:
         "p50_latency_ms": 1e3 * float(np.median(per_step)),
     }
 
+    if world == 1:
+        # ---- the same request with repetition_penalty 1.0 (SURVEY.md 8d asks for both; the headline uses the API default 1.2)
+        np_lat = []
+        for i in range(3):
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            model.generate_tokens_device(audio, lens_dev, lens, budgets, "English", repetition_penalty=1.0)
+            torch.cuda.synchronize()
+            if i:
+                np_lat.append(time.perf_counter() - s0)
+        line["no_repetition_penalty"] = {"value": B * args.clip_seconds / float(np.median(np_lat)), "unit": "audio-s/wall-s",
+                                         "p50_latency_ms": 1e3 * float(np.median(np_lat))}
     if world == 1 and B > 1:
         # ---- BASELINE.json configs[1]: batch 1, one 30 s clip, same decode budget -> latency
         a1, l1d, l1 = q.audio.pack_audio([synth_clip(0, n)], dev)
