@@ -88,7 +88,7 @@ class _Embedding:
 class DecodeWorkspace:
     """Device state of one decode batch; pointers are stable so one hipGraph serves every step."""
 
-    def __init__(self, cfg: TextDecoderConfig, B: int, max_out: int, device):
+    def __init__(self, cfg: TextDecoderConfig, B: int, max_out: int, device, fp8: bool = False):
         import torch
         i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=device)          # noqa: E731
         bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=device)        # noqa: E731
@@ -111,8 +111,9 @@ class DecodeWorkspace:
             "qkv": ops.pick_splits(qkvd, H), "o": ops.pick_splits(H, qd),
             "gu": ops.pick_splits(2 * I, H), "down": ops.pick_splits(H, I),
         }
-        self.geo = {"qkv": ops.gemm_geometry(qkvd, H), "o": ops.gemm_geometry(H, qd), "down": ops.gemm_geometry(H, I),
-                    "gu": ops.gemm_geometry(2 * I, H, swiglu=True), "head": ops.gemm_geometry(cfg.vocab_size, H, direct=True)}
+        self.geo = {"qkv": ops.gemm_geometry(qkvd, H, fp8=fp8), "o": ops.gemm_geometry(H, qd, fp8=fp8),
+                    "down": ops.gemm_geometry(H, I, fp8=fp8), "gu": ops.gemm_geometry(2 * I, H, swiglu=True, fp8=fp8),
+                    "head": ops.gemm_geometry(cfg.vocab_size, H, direct=True, fp8=fp8)}
         n_slab = max(self.splits["qkv"] * qkvd, self.splits["o"] * H, self.splits["gu"] * 2 * I, self.splits["down"] * H,
                      self.geo["qkv"][0] * qkvd, self.geo["o"][0] * H, self.geo["down"][0] * H)
         self.slab = torch.empty((n_slab * B,), dtype=torch.float32, device=device)
@@ -288,7 +289,7 @@ class TextDecoder:
         if ws is None:
             if len(self._ws) > 16:
                 self._ws.clear()
-            ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device)
+            ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device, fp8=getattr(self, "weight_dtype", "bf16") == "fp8")
         return ws
 
     def batch_cache(self, B: int, Lmax: int) -> KVCache:
