@@ -122,14 +122,17 @@ class DecodeWorkspace:
         self.slab2 = torch.empty_like(self.slab) if self.fused_norm else None
         self.h2 = torch.empty_like(self.h) if self.fused_norm else None
         self.graph = None
+        self.graph_multi = None
         self.graph_key = None
+        self.graph_uses = 0
 
     def __del__(self):
-        if getattr(self, "graph", None):
-            try:
-                _lib.load().q3asr_graph_destroy(self.graph)
-            except Exception:
-                pass
+        for g in (getattr(self, "graph", None), getattr(self, "graph_multi", None)):
+            if g:
+                try:
+                    _lib.load().q3asr_graph_destroy(g)
+                except Exception:
+                    pass
 
 
 class TextDecoder:
@@ -434,27 +437,42 @@ class TextDecoder:
                  int(s["repetition_context_size"]), int(s.get("seed", 0)), ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID, ops.sp())
 
     # ------------------------------------------------------------------ hipGraph
+    MULTI_STEPS = 4     # decode steps per launch of the second graph (a replay boundary costs ~8 us of idle GPU)
+
     def capture_step(self, ws: DecodeWorkspace, cache: KVCache, sampling: dict) -> None:
         import torch
         # the graph bakes raw pointers: key it on the addresses it captured, not on Python object identity
         key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.max_len, tuple(sorted(sampling.items())))
         if ws.graph is not None and ws.graph_key == key:
+            ws.graph_uses += 1
+            if ws.graph_multi is None and ws.graph_uses >= 2:        # a workspace that keeps coming back earns the long graph
+                ws.graph_multi = self._capture(ws, cache, sampling, self.MULTI_STEPS)
             return
-        if ws.graph is not None:
-            _lib.call("q3asr_graph_destroy", ws.graph)
-            ws.graph = None
+        for g in (ws.graph, ws.graph_multi):
+            if g is not None:
+                _lib.call("q3asr_graph_destroy", g)
+        ws.graph = ws.graph_multi = None
+        ws.graph, ws.graph_key, ws.graph_uses = self._capture(ws, cache, sampling, 1), key, 1
+
+    def _capture(self, ws: DecodeWorkspace, cache: KVCache, sampling: dict, n_steps: int):
+        """Record n_steps consecutive decode steps into one graph (stream capture records, it does not run them)."""
+        import torch
         stream = torch.cuda.current_stream()
         _lib.call("q3asr_graph_begin", C.c_void_p(stream.cuda_stream))
         try:
-            self.decode_step(ws, cache, sampling)
+            for _ in range(n_steps):
+                self.decode_step(ws, cache, sampling)
         finally:
             g = C.c_void_p()
             _lib.call("q3asr_graph_end", C.c_void_p(stream.cuda_stream), C.byref(g))
-        ws.graph, ws.graph_key = g, key
+        return g
 
-    def replay_step(self, ws: DecodeWorkspace) -> None:
+    def replay_step(self, ws: DecodeWorkspace, multi: bool = False) -> int:
+        """Replay one captured step, or MULTI_STEPS of them when `multi` and the long graph exists.  Returns the steps run."""
         import torch
-        _lib.call("q3asr_graph_launch", ws.graph, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        use_multi = multi and ws.graph_multi is not None
+        _lib.call("q3asr_graph_launch", ws.graph_multi if use_multi else ws.graph, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return self.MULTI_STEPS if use_multi else 1
 
     # ------------------------------------------------------------------ reference-shaped call (batch 1)
     def __call__(self, inputs, cache: Optional[KVCache] = None, is_embeds: bool = False):

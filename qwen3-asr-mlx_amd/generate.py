@@ -132,11 +132,14 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
                 done = 1
                 if steps > 1:
                     decoder.capture_step(ws, cache, sampling)
+                checked = done
                 while done < steps:
-                    decoder.replay_step(ws)
-                    done += 1
-                    if done % 16 == 0 and bool(ws.finished.all()):
-                        break
+                    # several steps per launch while that cannot overshoot the budget
+                    done += decoder.replay_step(ws, multi=steps - done >= decoder.MULTI_STEPS)
+                    if done - checked >= 16:
+                        checked = done
+                        if bool(ws.finished.all()):
+                            break
             torch.cuda.current_stream().wait_stream(side)
         else:
             while done < steps:
