@@ -197,6 +197,25 @@ def test_transcribe_batch_over_max_batch_runs_two_lanes(dev, small):
     assert par == seq and len(par) == len(xs)
 
 
+def test_small_batch_fused_norm_path_equals_separate_launches(dev, small, full):
+    """Batch <= 2 runs the residual + RMSNorm inside the consuming GEMMs: identical tokens with the fusion switched off,
+    on the small config and at the 1.7B shapes (where the tuned geometry applies)."""
+    for cfg, state, model in (small, full):
+        xs = [signal("speechlike", 48000, seed=31), signal("noise", 32000, seed=32)]
+        for batch in (xs[:1], xs):
+            fused = model.generate_tokens(batch, [10] * len(batch), "English")
+            model._decoder.fuse_norm = False
+            try:
+                for ws in model._decoder._ws.values():
+                    ws.graph_key = None                   # recapture without the fusion
+                plain = model.generate_tokens(batch, [10] * len(batch), "English")
+            finally:
+                model._decoder.fuse_norm = True
+                for ws in model._decoder._ws.values():
+                    ws.graph_key = None
+            assert fused == plain
+
+
 def test_sampling_path_runs_and_respects_filters(dev, small):
     cfg, state, model = small
     x = signal("speechlike", 32000)
