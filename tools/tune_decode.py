@@ -63,6 +63,9 @@ def measure():
     return best * 1e6
 
 
+MIN_WGS = int(sys.argv[5]) if len(sys.argv) > 5 else 192
+
+
 def candidates(N, K, swiglu, direct=False):
     out = []
     kq = 64 if WDT == "fp8" else 32
@@ -77,7 +80,7 @@ def candidates(N, K, swiglu, direct=False):
             continue
         per_wg = (1 if ks else waves) * rt
         wgs = -(-(N // 16) // per_wg) * S
-        if 192 <= wgs <= (16384 if direct else 2048) and K // S >= 128:
+        if MIN_WGS <= wgs <= (16384 if direct else 2048) and K // S >= 128:
             out.append((S, waves, rt, ks))
     return out
 
@@ -99,6 +102,9 @@ for name, N, K, sw, direct in shapes:
             print("  ", c, "failed:", str(e)[:80])
     res.sort()
     print(f"{name} (N={N}, K={K}) current {cur}: best 5 of {len(res)}: " + ", ".join(f"{c} {u:.1f}" for u, c in res[:5]), flush=True)
+    one = [(u, c) for u, c in res if c[0] == 1]
+    if one and not (sw or direct):
+        print("   unsplit (n_splits = 1): " + ", ".join(f"{c} {u:.1f}" for u, c in one[:4]), flush=True)
     ops._TUNED[(N, K)] = res[0][1] if res and res[0][0] < base - 2 else cur
     base = min(base, res[0][0]) if res else base
 print("final table:", {k: v for k, v in ops._TUNED.items()})
