@@ -76,3 +76,34 @@ def run_sharded(run_fn: Callable[[list, list], list], audios: Optional[Sequence[
             n = int(g[j, 0])
             result[i] = g[j, 1: 1 + n].tolist()
     return result
+
+
+def transcribe_sharded(model, audios: Optional[Sequence], language: Optional[str] = None, max_tokens: Optional[int] = None,
+                       chunk_duration: float = 1200.0, device="cpu", group=None, **sampling) -> Optional[list]:
+    """`Qwen3ASR.transcribe_batch` over all ranks of `group`: rank 0 passes the request (others `audios=None`), plans the
+    decode jobs -- one per utterance, one per low-energy-split segment of long-form audio (reference model.py:382-447) --
+    and the jobs, not the utterances, are dealt to the ranks, so a single long recording spreads over every GPU.
+    Returns the `TranscriptionResult`s on rank 0 (None elsewhere); equal to the single-process result."""
+    import torch.distributed as dist
+    from .model import TranscriptionResult, plan_jobs
+    rank = dist.get_rank(group)
+    lang = model._resolve_language(language)
+    jobs = seg_of = samples = None
+    if rank == 0:
+        samples = [model._as_samples(a) for a in audios]
+        jobs, seg_of = plan_jobs(samples, chunk_duration, max_tokens)
+    toks = run_sharded(lambda a, m: model.generate_tokens(a, m, lang, **sampling), [j[1] for j in jobs] if rank == 0 else None,
+                       [j[2] for j in jobs] if rank == 0 else None, device=device, group=group)
+    if rank != 0:
+        return None
+    texts = [model._decode_output(t) for t in toks]
+    out = []
+    for i, s in enumerate(samples):
+        if len(s) == 0:
+            out.append(TranscriptionResult(text="", language="Unknown", duration=0.0))
+            continue
+        parts = [texts[j] for j in seg_of[i]]
+        long_form = len(s) / 16_000 > chunk_duration
+        out.append(TranscriptionResult(text=" ".join(t for t in parts if t) if long_form else parts[0], language=lang,
+                                       duration=len(s) / 16_000))
+    return out

@@ -61,6 +61,30 @@ def _find_split_points(samples: np.ndarray, chunk_samples: int, search_samples: 
     return points
 
 
+def plan_jobs(samples: Sequence[np.ndarray], chunk_duration: float, max_tokens: Optional[int]):
+    """Decode jobs of a request: one per utterance, or one per low-energy-split segment for audio longer than
+    `chunk_duration` (reference model.py:313,382-447; a segment's budget is max(256, 50 tokens per second)).
+    Returns (jobs, seg_of): jobs = [(utterance index, samples, max_tokens)], seg_of[utterance] = its job indices
+    (empty utterances have none)."""
+    jobs: list = []
+    seg_of: dict[int, list[int]] = {}
+    for i, s in enumerate(samples):
+        if len(s) == 0:
+            continue
+        dur = len(s) / 16_000
+        if dur > chunk_duration:
+            prev = 0
+            for sp in _find_split_points(s, int(chunk_duration * 16_000), int(5.0 * 16_000)) + [len(s)]:
+                seg, prev = s[prev:sp], sp
+                if len(seg):
+                    seg_of.setdefault(i, []).append(len(jobs))
+                    jobs.append((i, seg, max(256, int(len(seg) / 16_000 * 50))))
+        else:
+            seg_of[i] = [len(jobs)]
+            jobs.append((i, s, max_tokens if max_tokens is not None else max(256, int(dur * 50))))
+    return jobs, seg_of
+
+
 class Qwen3ASR:
     """Qwen3-ASR speech-to-text on one MI355X (reference model.py:121-447)."""
 
@@ -120,28 +144,10 @@ class Qwen3ASR:
             samples = [self._as_samples(a) for a in audios]
             lang = self._resolve_language(language)
             results: list[Optional[TranscriptionResult]] = [None] * len(samples)
-            jobs = []                                            # (result index, segment samples, max_tokens)
-            seg_of: dict[int, list[int]] = {}
-            for i, s in enumerate(samples):
-                if len(s) == 0:
+            jobs, seg_of = plan_jobs(samples, chunk_duration, max_tokens)
+            for i, smp in enumerate(samples):
+                if len(smp) == 0:
                     results[i] = TranscriptionResult(text="", language="Unknown", duration=0.0)
-                    continue
-                dur = len(s) / 16_000
-                if dur > chunk_duration:                         # model.py:313,382-447
-                    cs = int(chunk_duration * 16_000)
-                    pts = _find_split_points(s, cs, int(5.0 * 16_000))
-                    prev = 0
-                    for sp in pts + [len(s)]:
-                        seg = s[prev:sp]
-                        prev = sp
-                        if len(seg) == 0:
-                            continue
-                        seg_of.setdefault(i, []).append(len(jobs))
-                        jobs.append((i, seg, max(256, int(len(seg) / 16_000 * 50))))
-                else:
-                    mt = max_tokens if max_tokens is not None else max(256, int(dur * 50))
-                    seg_of[i] = [len(jobs)]
-                    jobs.append((i, s, mt))
             texts = self._run_jobs(jobs, lang, temperature, top_p, top_k, repetition_penalty, repetition_context_size)
             for i, idxs in seg_of.items():
                 dur = len(samples[i]) / 16_000

@@ -65,3 +65,68 @@ def test_assignment_balances_and_covers():
     assert parts[0][0] == 1 and [len(p) for p in parts] == [2, 2, 1, 1]
     assert [len(p) for p in qd.assign([480000] * 256, 8)] == [32] * 8
     assert qd.assign([], 2) == [[], []]
+
+
+class _StandInModel:
+    """Duck-typed Qwen3ASR for the host logic of transcribe_sharded: tokens are a function of the samples only."""
+
+    def _resolve_language(self, language):
+        return "English" if language is None else language
+
+    @staticmethod
+    def _as_samples(a):
+        return np.asarray(a, dtype=np.float32)
+
+    def generate_tokens(self, audios, budgets, lang, **kw):
+        return _fake_run(audios, budgets)
+
+    def _decode_output(self, toks):
+        return "-".join(str(t) for t in toks)
+
+
+def _long_request():
+    rng = np.random.default_rng(5)
+    env = lambda n: (0.05 + np.abs(np.sin(np.arange(n) / 16000.0 * 2.1))).astype(np.float32)      # noqa: E731
+    return [rng.standard_normal(n).astype(np.float32) * env(n) for n in (16000 * 70, 3000, 0, 16000 * 31)]
+
+
+def _worker_longform(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qwen3_asr_mlx_amd import dist as qd
+    res = qd.transcribe_sharded(_StandInModel(), _long_request() if rank == 0 else None, chunk_duration=20.0)
+    if rank == 0:
+        q.put([(r.text, r.language, r.duration) for r in res])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_longform_segments_are_dealt_across_ranks():
+    """transcribe_sharded: segments of long recordings (20 s chunks here) go to different ranks; texts are re-joined in
+    order and equal the single-process plan + run."""
+    from qwen3_asr_mlx_amd.model import plan_jobs
+    audios = _long_request()
+    m = _StandInModel()
+    jobs, seg_of = plan_jobs(audios, 20.0, None)
+    assert len(seg_of[0]) >= 3 and len(seg_of[3]) == 2 and len(seg_of[1]) == 1 and 2 not in seg_of
+    texts = [m._decode_output(t) for t in _fake_run([j[1] for j in jobs], [j[2] for j in jobs])]
+    want = []
+    for i, a in enumerate(audios):
+        if len(a) == 0:
+            want.append(("", "Unknown", 0.0))
+        else:
+            parts = [texts[j] for j in seg_of[i]]
+            want.append((" ".join(parts) if len(a) / 16000 > 20.0 else parts[0], "English", len(a) / 16000))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker_longform, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == want
