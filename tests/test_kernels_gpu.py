@@ -189,6 +189,7 @@ def test_gemm_swiglu(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 384), (1000, 768, 1024), (2050, 1280, 2048), (515, 256, 6144),
+                                   (777, 992, 512),               # ragged N as well (last tile column 224 wide)
                                    (4396, 4096, 1024)])           # 288 tiles: the 8-phase kernel walks two tiles per workgroup
 def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     """The 128x128 kernel, the 256x256 register-staged kernel and the 256x256 8-phase LDS-DMA kernel accumulate every
