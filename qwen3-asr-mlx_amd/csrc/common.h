@@ -34,8 +34,27 @@ __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }          // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
 __device__ __forceinline__ float round_bf(float x) { return (float)(bf16)x; }
 
-// exact-erf GELU (MLX nn.gelu; encoder.py:118,273-275,320)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (MLX nn.gelu; encoder.py:118,273-275,320): x * Phi(x) with Phi from the complementary error function in
+// Chebyshev-fitted form erfc(z) = t exp(-z^2 + P(t)), t = 1 / (1 + z/2), z >= 0 -- fractional error < 1.2e-7 everywhere
+// (Numerical Recipes erfcc), so the negative tail keeps relative accuracy, which 1 + erf(.) would lose; branch-free, one
+// reciprocal and one exponential (the library erff costs about three times as many instructions and the GELU epilogues of
+// conv1 / conv2 / conv3 / fc1 are VALU-bound).  Outputs are rounded to bf16 by every caller.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.5f * z);
+    float p = 0.17087277f;
+    p = fmaf(p, t, -0.82215223f);
+    p = fmaf(p, t, 1.48851587f);
+    p = fmaf(p, t, -1.13520398f);
+    p = fmaf(p, t, 0.27886807f);
+    p = fmaf(p, t, -0.18628806f);
+    p = fmaf(p, t, 0.09678418f);
+    p = fmaf(p, t, 0.37409196f);
+    p = fmaf(p, t, 1.00002368f);
+    p = fmaf(p, t, -1.26551223f);
+    const float half_erfc = 0.5f * t * __expf(fmaf(-z, z, p));           // Phi(-|x|)
+    return x * (x < 0.f ? half_erfc : 1.0f - half_erfc);
+}
 
 // ---- wave reductions (wave = 64 lanes) -----------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
