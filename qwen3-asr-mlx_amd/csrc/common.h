@@ -41,7 +41,7 @@ __device__ __forceinline__ float round_bf(float x) { return (float)(bf16)x; }
 // conv1 / conv2 / conv3 / fc1 are VALU-bound).  Outputs are rounded to bf16 by every caller.
 __device__ __forceinline__ float gelu_erf(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.5f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.5f * z);            // v_rcp_f32 (1 ulp): inside the fit's 1.2e-7
     float p = 0.17087277f;
     p = fmaf(p, t, -0.82215223f);
     p = fmaf(p, t, 1.48851587f);
