@@ -208,3 +208,76 @@ def test_encoder_oracle_shapes_and_block_locality():
     pe = oracle.sinusoid_table(1500, 64)
     assert pe.shape == (1500, 64) and torch.equal(pe[:13], oracle.sinusoid_table(13, 64))     # test_encoder.py:171-198
     assert torch.equal(pe[0], torch.cat([torch.zeros(32), torch.ones(32)]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Second, independent statement of the same architecture: the PyTorch implementation that ships with `transformers`
+# (modeling_qwen3_asr.py for the audio tower, Qwen3ForCausalLM for the text side), instantiated from a local tiny config
+# with the SAME random weights -- nothing is fetched.  It pins the oracle's structure (conv flatten order, per-chunk
+# positional embedding, pad-token strip, attention windows; QK-norm before RoPE, half-split RoPE, GQA, tied head,
+# cached == full context); the MLX-specific bf16 rounding points stay as read from the reference.
+def _small_weights():
+    from qwen3_asr_mlx_amd import synth
+    cfg = synth.small_config()
+    st = synth.random_state(cfg, seed=0, bias_std=0.02, norm_jitter=0.1)
+    We = {k[len("audio_tower."):]: v.float() for k, v in st.items() if k.startswith("audio_tower.")}
+    Wd = {k[len("model."):]: v.float() for k, v in st.items() if k.startswith("model.")}
+    return cfg, We, Wd
+
+
+def test_encoder_oracle_matches_transformers_implementation():
+    m = pytest.importorskip("transformers.models.qwen3_asr.modeling_qwen3_asr")
+    c = pytest.importorskip("transformers.models.qwen3_asr.configuration_qwen3_asr")
+    import oracle
+    from signals import signal
+    cfg, We, _ = _small_weights()
+    a = cfg.audio_encoder
+    ec = c.Qwen3ASREncoderConfig(num_mel_bins=a.num_mel_bins, encoder_layers=a.encoder_layers, encoder_attention_heads=a.encoder_attention_heads,
+                                 encoder_ffn_dim=a.encoder_ffn_dim, d_model=a.d_model, n_window=a.n_window, output_dim=a.output_dim,
+                                 n_window_infer=a.n_window_infer, downsample_hidden_size=a.downsample_hidden_size)
+    ec._attn_implementation = "eager"
+    enc = m.Qwen3ASREncoder(ec).eval().float()
+    sd = {k: (v.permute(0, 3, 1, 2).contiguous() if k.startswith("conv2d") and k.endswith("weight") else v)     # (O,kH,kW,I) -> (O,I,kH,kW)
+          for k, v in We.items() if not k.startswith("proj")}
+    enc.load_state_dict(sd, strict=True)
+    for n in (16000 * 3 + 777, 16000 * 11):                    # one window / several 104-token windows, ragged last chunk
+        mel = oracle.log_mel_spectrogram(signal("speechlike", n, seed=3))
+        F = mel.shape[1]
+        Fp = (F + 99) // 100 * 100
+        feat = torch.zeros(1, 128, Fp)
+        feat[0, :, :F] = torch.from_numpy(mel)
+        mask = torch.zeros(1, Fp, dtype=torch.long)
+        mask[0, :F] = 1
+        with torch.no_grad():
+            h = enc(feat, mask).last_hidden_state
+            theirs = torch.nn.functional.gelu(h @ We["proj1.weight"].T + We["proj1.bias"]) @ We["proj2.weight"].T + We["proj2.bias"]
+        mine = oracle.encoder_forward(torch.from_numpy(mel), We, a.encoder_attention_heads, a.n_window, a.n_window_infer, gpu_rounding=False)
+        assert mine.shape == theirs.shape
+        torch.testing.assert_close(mine, theirs, atol=2e-6, rtol=1e-5)
+
+
+def test_decoder_oracle_matches_transformers_qwen3(monkeypatch):
+    tr = pytest.importorskip("transformers")
+    import oracle
+    import oracle.decoder as od
+    cfg, _, Wd = _small_weights()
+    t = cfg.text_decoder
+    hc = tr.Qwen3Config(vocab_size=t.vocab_size, hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                        num_hidden_layers=t.num_hidden_layers, num_attention_heads=t.num_attention_heads,
+                        num_key_value_heads=t.num_key_value_heads, head_dim=t.head_dim, hidden_act="silu", max_position_embeddings=4096,
+                        rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta, tie_word_embeddings=True, attention_bias=False,
+                        use_sliding_window=False, attn_implementation="eager")
+    hf = tr.Qwen3ForCausalLM(hc).eval().float()
+    sd = {"model." + k: v for k, v in Wd.items()}
+    sd["lm_head.weight"] = Wd["embed_tokens.weight"]
+    hf.load_state_dict(sd, strict=True)
+    emb = torch.randn(1, 37, t.hidden_size, generator=torch.Generator().manual_seed(0)) * 0.5
+    with torch.no_grad():
+        ref = hf(inputs_embeds=emb).logits[0]
+    monkeypatch.setattr(od, "bf", lambda x: x)                 # fp32 at every op: structure, not rounding
+    dec = oracle.DecoderOracle(Wd, t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.rms_norm_eps, t.rope_theta)
+    full = dec.forward(emb[0].clone(), last_only=False)
+    torch.testing.assert_close(full, ref, atol=2e-5, rtol=1e-5)
+    dec.reset()                                                # prefill 30 tokens, then 7 cached single steps
+    inc = torch.cat([dec.forward(emb[0, :30].clone(), last_only=False)] + [dec.forward(emb[0, i:i + 1].clone(), last_only=False) for i in range(30, 37)])
+    torch.testing.assert_close(inc, ref, atol=2e-5, rtol=1e-5)
