@@ -281,3 +281,63 @@ def test_decoder_oracle_matches_transformers_qwen3(monkeypatch):
     dec.reset()                                                # prefill 30 tokens, then 7 cached single steps
     inc = torch.cat([dec.forward(emb[0, :30].clone(), last_only=False)] + [dec.forward(emb[0, i:i + 1].clone(), last_only=False) for i in range(30, 37)])
     torch.testing.assert_close(inc, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_whole_model_oracle_matches_transformers_conditional_generation(monkeypatch):
+    """mel -> encoder -> prompt -> audio-pad merge -> decoder logits, oracle vs transformers' Qwen3ASRForConditionalGeneration
+    on the same random weights: pins prepare_inputs / build_prompt placement and the composition of the stages."""
+    m = pytest.importorskip("transformers.models.qwen3_asr.modeling_qwen3_asr")
+    c = pytest.importorskip("transformers.models.qwen3_asr.configuration_qwen3_asr")
+    import oracle
+    import oracle.decoder as od
+    import importlib
+    og = importlib.import_module("oracle.generate")
+    from qwen3_asr_mlx_amd.tokenizer import AUDIO_PAD_TOKEN_ID, build_prompt
+    from signals import signal
+    cfg, We, Wd = _small_weights()
+    a, t = cfg.audio_encoder, cfg.text_decoder
+    hc = c.Qwen3ASRConfig(
+        audio_config=dict(num_mel_bins=a.num_mel_bins, encoder_layers=a.encoder_layers, encoder_attention_heads=a.encoder_attention_heads,
+                          encoder_ffn_dim=a.encoder_ffn_dim, d_model=a.d_model, n_window=a.n_window, output_dim=a.output_dim,
+                          n_window_infer=a.n_window_infer, downsample_hidden_size=a.downsample_hidden_size),
+        text_config=dict(model_type="qwen3", vocab_size=t.vocab_size, hidden_size=t.hidden_size, intermediate_size=t.intermediate_size,
+                         num_hidden_layers=t.num_hidden_layers, num_attention_heads=t.num_attention_heads,
+                         num_key_value_heads=t.num_key_value_heads, head_dim=t.head_dim, hidden_act="silu", max_position_embeddings=4096,
+                         rms_norm_eps=t.rms_norm_eps, rope_theta=t.rope_theta, tie_word_embeddings=True, attention_bias=False,
+                         use_sliding_window=False),
+        audio_token_id=AUDIO_PAD_TOKEN_ID)
+    hc._attn_implementation = "eager"
+    hf = m.Qwen3ASRForConditionalGeneration(hc).eval().float()
+    sd = {}
+    for k, v in We.items():
+        if k.startswith("proj"):
+            sd["model.multi_modal_projector.linear_" + k[4:]] = v
+        else:
+            sd["model.audio_tower." + k] = v.permute(0, 3, 1, 2).contiguous() if k.startswith("conv2d") and k.endswith("weight") else v
+    sd.update({"model.language_model." + k: v for k, v in Wd.items()})
+    sd["lm_head.weight"] = Wd["embed_tokens.weight"]
+    hf.load_state_dict(sd, strict=True)
+
+    monkeypatch.setattr(od, "bf", lambda x: x)                 # fp32 at every op: structure, not rounding
+    monkeypatch.setattr(og, "bf", lambda x: x)
+    mel = oracle.log_mel_spectrogram(signal("speechlike", 16000 * 5 + 321, seed=5))
+    F = mel.shape[1]
+    Fp = (F + 99) // 100 * 100
+    feat = torch.zeros(1, 128, Fp)
+    feat[0, :, :F] = torch.from_numpy(mel)
+    mask = torch.zeros(1, Fp, dtype=torch.long)
+    mask[0, :F] = 1
+    enc = oracle.encoder_forward(torch.from_numpy(mel), We, a.encoder_attention_heads, a.n_window, a.n_window_infer, gpu_rounding=False)
+    ids = build_prompt(enc.shape[0], [6364])                   # " English"
+    with torch.no_grad():
+        ref = hf(input_ids=torch.tensor([ids]), input_features=feat, input_features_mask=mask).logits[0]
+    emb = oracle.prepare_inputs(enc, ids, Wd["embed_tokens.weight"])
+    dec = oracle.DecoderOracle(Wd, t.num_attention_heads, t.num_key_value_heads, t.head_dim, t.rms_norm_eps, t.rope_theta)
+    mine = dec.forward(emb, last_only=False)
+    assert mine.shape == ref.shape
+    torch.testing.assert_close(mine, ref, atol=3e-5, rtol=1e-5)
+    assert int(mine[-1].argmax()) == int(ref[-1].argmax())
+    with pytest.raises(ValueError):                            # both refuse a pad count that differs from the encoder length
+        oracle.prepare_inputs(enc[:-1], ids, Wd["embed_tokens.weight"])
+    with pytest.raises(ValueError), torch.no_grad():
+        hf(input_ids=torch.tensor([build_prompt(enc.shape[0] + 1, [6364])]), input_features=feat, input_features_mask=mask)
