@@ -13,6 +13,10 @@ LIB = HERE / "libq3asr_hip.so"
 SOURCES = ["core.hip", "mel.hip", "gemm.hip", "norm.hip", "elementwise.hip", "attn.hip", "skinny.hip", "decode.hip", "sampling.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I", str(HERE.parent / "include")]
+if os.environ.get("Q3ASR_PACKED_F32", "0") != "1":
+    # no v_pk_*_f32: see DESIGN.md section 4 (wrong results beside a foreign MFMA kernel).  The host pass prints "not a
+    # recognized feature" for it and ignores it.
+    FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _stale(obj: Path, deps) -> bool:

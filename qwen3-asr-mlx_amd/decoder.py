@@ -210,15 +210,17 @@ class TextDecoder:
         self.embed_tokens = _Embedding(w["embed"])
 
     # ------------------------------------------------------------------ prefill (hot path)
-    def _prefill_plan(self, seq_lens: tuple, Lmax: int):
-        key = (seq_lens, Lmax)
+    def _prefill_plan(self, seq_lens: tuple, Lmax: int, slots: Optional[tuple] = None):
+        """Index vectors of one packed prefill.  `slots`: cache rows the sequences go to (default 0..n-1)."""
+        slots = tuple(range(len(seq_lens))) if slots is None else slots
+        key = (seq_lens, Lmax, slots)
         pl = self._plans.get(key)
         if pl is None:
             import torch
             cfg, dev = self.config, self.device
             row_b, row_pos, starts, last = [], [], [], []
             m = 0
-            for b, t in enumerate(seq_lens):
+            for b, t in zip(slots, seq_lens):
                 starts.append(m)
                 row_b += [b] * t
                 row_pos += list(range(t))
@@ -227,18 +229,24 @@ class TextDecoder:
             i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
             pl = {"row_b": i32(row_b), "row_pos": i32(row_pos), "seg_start": i32(starts), "seg_len": i32(list(seq_lens)),
                   "last": i32(last), "M": m, "max_len": max(seq_lens),
-                  "kv_off": torch.tensor([b * cfg.num_key_value_heads * Lmax * cfg.head_dim for b in range(len(seq_lens))],
+                  "kv_off": torch.tensor([b * cfg.num_key_value_heads * Lmax * cfg.head_dim for b in slots],
                                          dtype=torch.int64, device=dev)}
             if len(self._plans) > 64:
                 self._plans.clear()
             self._plans[key] = pl
         return pl
 
-    def _layers_prefill(self, h, cache: KVCache, seq_lens: Sequence[int]):
+    def _layers_prefill(self, h, cache: KVCache, seq_lens: Sequence[int], slots: Optional[Sequence[int]] = None):
         """h bf16 [M][H] (packed rows of all sequences, positions start at 0) -> updated in place."""
         import torch
         cfg, w, dev = self.config, self.w, self.device
-        pl = self._prefill_plan(tuple(int(t) for t in seq_lens), cache.max_len)
+        if slots is not None:
+            slots = tuple(int(s) for s in slots)
+            if len(slots) != len(seq_lens) or len(set(slots)) != len(slots) or min(slots) < 0 or max(slots) >= cache.batch:
+                raise ValueError(f"prefill: slots {slots} must be {len(seq_lens)} distinct rows of a cache of {cache.batch}")
+        if max(seq_lens) > cache.max_len:
+            raise ValueError(f"prefill: a sequence of {max(seq_lens)} tokens does not fit a cache of {cache.max_len}")
+        pl = self._prefill_plan(tuple(int(t) for t in seq_lens), cache.max_len, slots)
         M, H, I = pl["M"], cfg.hidden_size, cfg.intermediate_size
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
@@ -263,15 +271,16 @@ class TextDecoder:
             ops.gemm(act, L["wdown"], M, H, I, h, res=h, res_kind=2, ldres=H)
         return pl
 
-    def prefill(self, embeds, seq_lens: Sequence[int], cache: KVCache, logits_out=None):
+    def prefill(self, embeds, seq_lens: Sequence[int], cache: KVCache, logits_out=None, slots: Optional[Sequence[int]] = None):
         """Packed prompt embeddings bf16 [sum T_b][H] -> bf16 logits of each sequence's LAST
         position [B][V] (the reference computes all T rows, decoder.py:251-252, and consumes only the
-        last, generate.py:279).  Fills cache positions 0..T_b-1."""
+        last, generate.py:279).  Fills cache positions 0..T_b-1 of cache rows `slots` (default 0..B-1; other rows of the
+        cache are left alone, so a sequence can be admitted while its neighbours are mid-decode)."""
         import torch
         cfg, w = self.config, self.w
         B = len(seq_lens)
         h = embeds.clone()
-        pl = self._layers_prefill(h, cache, seq_lens)
+        pl = self._layers_prefill(h, cache, seq_lens, slots)
         xl = torch.empty((B, cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
         ops.rmsnorm(h, w["norm"], xl, B, cfg.hidden_size, cfg.rms_norm_eps, row_idx=pl["last"])
         if logits_out is None:
@@ -435,6 +444,16 @@ class TextDecoder:
                  ws.max_out, ops.ptr(ws.n_gen), ops.ptr(ws.finished), ops.ptr(ws.cur_tok), ops.ptr(ws.pos), ops.ptr(ws.max_new),
                  float(s["temperature"]), float(s["top_p"]), int(s["top_k"]), float(s["repetition_penalty"]),
                  int(s["repetition_context_size"]), int(s.get("seed", 0)), ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID, ops.sp())
+
+    def sample_rows(self, ws: DecodeWorkspace, logits_row, row: int, s: dict) -> None:
+        """sample_step for ONE row of the workspace from a separate logits vector (a sequence admitted into a running batch
+        draws its first token without touching its neighbours): same kernel, batch 1, pointers offset to `row`."""
+        V = self.config.vocab_size
+        ops.call("q3asr_sample_step", ops.ptr(logits_row), V, 1, V, ops.ptr(ws.out_tokens[row]),
+                 ws.max_out, ops.ptr(ws.n_gen[row:]), ops.ptr(ws.finished[row:]), ops.ptr(ws.cur_tok[row:]), ops.ptr(ws.pos[row:]),
+                 ops.ptr(ws.max_new[row:]), float(s["temperature"]), float(s["top_p"]), int(s["top_k"]),
+                 float(s["repetition_penalty"]), int(s["repetition_context_size"]), int(s.get("seed", 0)) + 0x9E3779B97F4A7C15 * (row + 1) & 0x7FFFFFFFFFFFFFFF,
+                 ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID, ops.sp())
 
     # ------------------------------------------------------------------ hipGraph
     MULTI_STEPS = 4     # decode steps per launch of the second graph (a replay boundary costs ~8 us of idle GPU)

@@ -153,6 +153,110 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
     return (out, ws, cache) if return_state else out
 
 
+def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence[Sequence[int]], max_tokens: Sequence[int],
+                        slots: int = 32, temperature: float = 0.0, top_p: float = 1.0, top_k: int = 0,
+                        repetition_penalty: float = 1.0, repetition_context_size: int = 100, seed: int = 0,
+                        check_every: int = 16, stats: Optional[dict] = None) -> list[list[int]]:
+    """Any number of sequences through `slots` decode rows: a row whose sequence has ended (EOS or budget) is handed to the
+    next waiting sequence, whose prompt is prefilled into that row of the KV cache while the other rows keep their state
+    (the reference decodes one utterance at a time, model.py:239).  `feats[i]`: encoder output
+    fp32 [N_i][H] of sequence i.  Sequences are admitted in the order given.  Greedy results equal generate_batch's
+    (and the reference loop's) token for token: a row's arithmetic does not depend on its neighbours, its row index or the
+    cache capacity.  With temperature > 0 the draws depend on the row a sequence lands in (reproducible, but not equal
+    to a standalone call)."""
+    import torch
+    from collections import deque
+    n = len(prompts)
+    if n == 0:
+        return []
+    if not (len(feats) == len(max_tokens) == n):
+        raise ValueError("generate_continuous: feats, prompts and max_tokens must have one entry per sequence")
+    mt = [int(m) for m in max_tokens]
+    if min(mt) < 1:
+        raise ValueError("max_tokens must be >= 1")
+    B = max(1, min(int(slots), n, 64))
+    seq_lens = [len(p) for p in prompts]
+    tok_counts = [int(f.shape[0]) for f in feats]
+    max_new = max(mt)
+    Lmax = (max(t + m for t, m in zip(seq_lens, mt)) + 63) // 64 * 64
+    cache = decoder.batch_cache(B, Lmax)
+    ws = decoder.workspace(B, max_new)
+    dev = decoder.device
+    V = decoder.config.vocab_size
+    sampling = {"temperature": float(temperature), "top_p": float(top_p), "top_k": int(top_k),
+                "repetition_penalty": float(repetition_penalty),
+                "repetition_context_size": int(repetition_context_size), "seed": int(seed)}
+    waiting = deque(range(n))
+    owner: list = [None] * B                     # sequence in each row
+    out: list = [None] * n
+    admit_logits = torch.empty((B, V), dtype=torch.bfloat16, device=dev)
+    st = {"steps": 0, "admissions": 0, "checks": 0, "row_steps_used": 0}
+
+    def admit(rows: list) -> None:
+        """Prefill the next waiting sequences into `rows`, reset those rows' counters, draw their first token."""
+        seqs = [waiting.popleft() for _ in rows]
+        for r, u in zip(rows, seqs):
+            owner[r] = u
+        packed = torch.cat([torch.as_tensor(feats[u]).to(dev, torch.float32).reshape(tok_counts[u], -1) for u in seqs])
+        embeds = _merge(packed, [prompts[u] for u in seqs], [tok_counts[u] for u in seqs], decoder)
+        full = len(rows) == B and rows == list(range(B))
+        logits = ws.logits if full else admit_logits
+        decoder.prefill(embeds, [seq_lens[u] for u in seqs], cache, logits_out=logits, slots=None if full else rows)
+        idx = torch.tensor(rows, dtype=torch.long, device=dev)
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
+        ws.n_gen.index_fill_(0, idx, 0)
+        ws.finished.index_fill_(0, idx, 0)
+        ws.pos.index_copy_(0, idx, i32([seq_lens[u] - 1 for u in seqs]))
+        ws.max_new.index_copy_(0, idx, i32([mt[u] for u in seqs]))
+        if full:
+            decoder.sample_step(ws, ws.logits, sampling)
+        else:
+            for j, r in enumerate(rows):                                    # first token (generate.py:278-286), this row only
+                decoder.sample_rows(ws, logits[j], r, sampling)
+        st["admissions"] += len(rows)
+
+    side = _side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ws.finished.fill_(1)                     # rows without a sequence stay inert
+        ws.n_gen.zero_()
+        admit(list(range(B)))
+        captured = False
+        while True:
+            fin, n_gen = ws.finished.tolist(), ws.n_gen.tolist()           # synchronises `side`
+            st["checks"] += 1
+            ended = [r for r in range(B) if owner[r] is not None and fin[r]]
+            if ended:
+                toks = ws.out_tokens[torch.tensor(ended, dtype=torch.long, device=dev)].cpu()
+                for j, r in enumerate(ended):
+                    out[owner[r]] = toks[j, : n_gen[r]].tolist()
+                    st["row_steps_used"] += n_gen[r]
+                    owner[r] = None
+            free = [r for r in range(B) if owner[r] is None]
+            if waiting and free:
+                admit(free[: len(waiting)])
+                continue                                                   # a budget of 1 ends at the first token
+            active = [r for r in range(B) if owner[r] is not None]
+            if not active:
+                break
+            # steps until the next look: no further than the first row that must end by budget
+            k = max(1, min(check_every, min(mt[owner[r]] - n_gen[r] for r in active)))
+            if not captured:
+                decoder.decode_step(ws, cache, sampling)                   # eager: loads code objects, a real step
+                decoder.capture_step(ws, cache, sampling)
+                captured = True
+                k -= 1
+                st["steps"] += 1
+            while k > 0:
+                d = decoder.replay_step(ws, multi=k >= decoder.MULTI_STEPS)
+                k -= d
+                st["steps"] += d
+    torch.cuda.current_stream().wait_stream(side)
+    if stats is not None:
+        stats.update(st, rows=B)
+    return out
+
+
 _streams: dict = {}
 
 

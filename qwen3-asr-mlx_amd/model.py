@@ -98,6 +98,8 @@ class Qwen3ASR:
         self._lock = threading.Lock()
         self.use_graph = True
         self.lanes = 2              # batches in flight when a request needs more than MAX_BATCH utterances/segments (1: sequential)
+        self.continuous = True      # such requests refill decode rows as sequences end (generate_continuous) instead of
+                                    # decoding fixed batches to their longest member
 
     @classmethod
     def from_pretrained(cls, model_id_or_path: str | Path, **kwargs) -> "Qwen3ASR":
@@ -224,6 +226,8 @@ class Qwen3ASR:
         """mel -> encoder -> prompt -> generate -> detokenise for a list of (idx, samples, max_tokens)."""
         texts: list[str] = [""] * len(jobs)
         order = sorted(range(len(jobs)), key=lambda j: -len(jobs[j][1]))      # similar lengths share a batch
+        if self.continuous and len(jobs) > self.MAX_BATCH:
+            return self._run_jobs_continuous(jobs, order, lang, temperature, top_p, top_k, repetition_penalty, repetition_context_size)
         batches = [order[s: s + self.MAX_BATCH] for s in range(0, len(order), self.MAX_BATCH)]
         seeds = [_next_seed() if temperature else 0 for _ in batches]         # fixed before any thread runs: reproducible
 
@@ -261,6 +265,65 @@ class Qwen3ASR:
                 errs.append(e)
 
         ths = [threading.Thread(target=worker, args=(lane,)) for lane in range(1, n_lanes + 1)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        if errs:
+            raise errs[0]
+        return texts
+
+    def _run_jobs_continuous(self, jobs, order, lang, temperature, top_p, top_k, repetition_penalty, repetition_context_size) -> list[str]:
+        """More jobs than decode rows: every lane takes every n-th job (longest first), encodes its share in batches and
+        decodes it through MAX_BATCH rows that are refilled as sequences end."""
+        import torch
+        from .decoder import set_lane
+        from .generate import generate_continuous
+        from .tokenizer import build_prompt
+        texts: list[str] = [""] * len(jobs)
+        n_lanes = max(1, min(self.lanes, len(jobs) // self.MAX_BATCH))
+        shares = [order[i::n_lanes] for i in range(n_lanes)]
+        seeds = [_next_seed() if temperature else 0 for _ in shares]
+        lang_ids = self._tokenizer.encode(f" {lang}")
+        dev = self._decoder.device
+        self.last_continuous_stats = [dict() for _ in shares]
+
+        def run(li: int) -> None:
+            sel = shares[li]
+            fe = get_frontend(dev)
+            feats, keep = [], []
+            for s0 in range(0, len(sel), self.MAX_BATCH):
+                part = sel[s0: s0 + self.MAX_BATCH]
+                audio, lens_dev, lens = pack_audio([jobs[j][1] for j in part], dev)
+                mel, n_frames = fe(audio, lens_dev, lens)
+                packed, counts = self._encoder.forward_batch(mel, n_frames)
+                keep.append(packed)
+                o = 0
+                for c in counts:
+                    feats.append(packed[o: o + c])
+                    o += c
+            prompts = [build_prompt(int(f.shape[0]), lang_ids) for f in feats]
+            toks = generate_continuous(self._decoder, feats, prompts, [jobs[j][2] for j in sel], self.MAX_BATCH, temperature, top_p,
+                                       top_k, repetition_penalty, repetition_context_size, seed=seeds[li],
+                                       stats=self.last_continuous_stats[li])
+            for j, t in zip(sel, toks):
+                texts[j] = self._decode_output(t)
+
+        if n_lanes == 1:
+            run(0)
+            return texts
+        errs: list = []
+
+        def worker(li: int) -> None:
+            try:
+                set_lane(li + 1)
+                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    run(li)
+                    torch.cuda.current_stream().synchronize()
+            except BaseException as e:                        # noqa: BLE001
+                errs.append(e)
+
+        ths = [threading.Thread(target=worker, args=(li,)) for li in range(n_lanes)]
         for th in ths:
             th.start()
         for th in ths:

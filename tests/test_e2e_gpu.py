@@ -188,13 +188,101 @@ def test_transcribe_batch_over_max_batch_runs_two_lanes(dev, small):
     """More utterances than one batch holds: the batches run two at a time on two lanes; texts equal the sequential run."""
     cfg, state, model = small
     xs = [signal("speechlike" if i % 3 else "noise", 16000 + 997 * (i % 11), seed=100 + i) for i in range(model.MAX_BATCH + 9)]
-    model.lanes = 1
+    model.lanes, model.continuous = 1, False
     try:
         seq = [r.text for r in model.transcribe_batch(xs, max_tokens=6)]
-    finally:
         model.lanes = 2
-    par = [r.text for r in model.transcribe_batch(xs, max_tokens=6)]
+        par = [r.text for r in model.transcribe_batch(xs, max_tokens=6)]
+    finally:
+        model.lanes, model.continuous = 2, True
     assert par == seq and len(par) == len(xs)
+    refill = [r.text for r in model.transcribe_batch(xs, max_tokens=6)]          # default: rows refilled as sequences end
+    assert refill == seq
+
+
+def _encoded(model, xs, dev):
+    from qwen3_asr_mlx_amd.audio import get_frontend, pack_audio
+    from qwen3_asr_mlx_amd.tokenizer import build_prompt
+    audio, lens_dev, lens = pack_audio(xs, dev)
+    mel, n_frames = get_frontend(dev)(audio, lens_dev, lens)
+    packed, counts = model._encoder.forward_batch(mel, n_frames)
+    feats, o = [], 0
+    for c in counts:
+        feats.append(packed[o: o + c])
+        o += c
+    lang_ids = model._tokenizer.encode(" English")
+    return feats, [build_prompt(int(c), lang_ids) for c in counts]
+
+
+@pytest.mark.parametrize("slots,check_every", [(4, 16), (3, 5), (32, 16)])
+def test_continuous_batching_equals_single_sequence_runs(dev, small, slots, check_every):
+    """13 sequences with ragged budgets through `slots` decode rows that are refilled (prefill into one
+    row of a live KV cache) as sequences end: token-identical to decoding each sequence alone."""
+    from qwen3_asr_mlx_amd.generate import generate_continuous
+    cfg, state, model = small
+    budgets = [1, 9, 3, 14, 6, 2, 11, 5, 8, 4, 12, 7, 23]
+    xs = [signal("speechlike" if i % 2 else "noise", 16000 + 2500 * (i % 7), seed=200 + i) for i in range(len(budgets))]
+    want = [model.generate_tokens([x], [m], "English")[0] for x, m in zip(xs, budgets)]
+    feats, prompts = _encoded(model, xs, dev)
+    stats: dict = {}
+    got = generate_continuous(model._decoder, feats, prompts, budgets, slots=slots, repetition_penalty=1.2, check_every=check_every,
+                              stats=stats)
+    assert got == want
+    assert [len(t) for t in got] == budgets
+    assert stats["admissions"] == len(budgets) and stats["rows"] == min(slots, len(budgets))
+    assert stats["row_steps_used"] == sum(budgets)
+    if slots < len(budgets):                             # fewer decode steps than fixed batches of `slots` in the given order need
+        fixed = sum(max(budgets[i: i + slots]) - 1 for i in range(0, len(budgets), slots))
+        assert stats["steps"] <= fixed
+
+
+def test_continuous_batching_through_the_model_api(dev, small):
+    """_run_jobs with more jobs than MAX_BATCH rows: two lanes, each refilling its rows; texts equal fixed batches."""
+    cfg, state, model = small
+    jobs = [(0, signal("speechlike" if i % 3 else "noise", 16000 + 1300 * (i % 9), seed=300 + i), 2 + (7 * i) % 19) for i in range(19)]
+    args = ("English", 0.0, 1.0, 0, 1.2, 100)
+    saved = model.MAX_BATCH
+    try:
+        model.MAX_BATCH = 4
+        model.continuous = False
+        fixed = model._run_jobs(jobs, *args)
+        model.continuous = True
+        refill = model._run_jobs(jobs, *args)
+        assert len(model.last_continuous_stats) == 2 and sum(s["admissions"] for s in model.last_continuous_stats) == len(jobs)
+        model.lanes = 1
+        one_lane = model._run_jobs(jobs, *args)
+    finally:
+        model.MAX_BATCH, model.lanes, model.continuous = saved, 2, True
+    assert refill == fixed and one_lane == fixed
+
+
+def test_prefill_into_chosen_cache_rows(dev, small):
+    """decoder.prefill(slots=...) writes only the named rows of the cache and returns the same logits as the default order."""
+    from qwen3_asr_mlx_amd.generate import _merge
+    cfg, state, model = small
+    dec = model._decoder
+    xs = [signal("speechlike", 30000, seed=41), signal("noise", 20000, seed=42)]
+    feats, prompts = _encoded(model, xs, dev)
+    counts = [int(f.shape[0]) for f in feats]
+    seq_lens = [len(p) for p in prompts]
+    emb = _merge(torch.cat(feats), prompts, counts, dec)
+    ref_cache = dec.batch_cache(2, 128)
+    ref = dec.prefill(emb, seq_lens, ref_cache).clone()
+    rk, rv = ref_cache.k.clone(), ref_cache.v.clone()
+    cache = dec.batch_cache(5, 128)
+    cache.k.fill_(7.0)
+    cache.v.fill_(-3.0)
+    got = dec.prefill(emb, seq_lens, cache, slots=[3, 1])
+    assert torch.equal(got, ref)
+    for j, r in enumerate([3, 1]):
+        assert torch.equal(cache.k[:, r, :, : seq_lens[j]], rk[:, j, :, : seq_lens[j]])
+        assert torch.equal(cache.v[:, r, :, : seq_lens[j]], rv[:, j, :, : seq_lens[j]])
+    for r in (0, 2, 4):
+        assert bool((cache.k[:, r] == 7.0).all()) and bool((cache.v[:, r] == -3.0).all())
+    with pytest.raises(ValueError):
+        dec.prefill(emb, seq_lens, cache, slots=[1, 1])
+    with pytest.raises(ValueError):
+        dec.prefill(emb, seq_lens, cache, slots=[0, 5])
 
 
 def test_small_batch_fused_norm_path_equals_separate_launches(dev, small, full):
@@ -473,3 +561,54 @@ def test_run_sharded_over_rccl_world1(dev, small):
         if created:
             dist.destroy_process_group()
     assert got == want
+
+
+def test_full_size_encoder_bit_identical_beside_decode_on_another_lane(dev, full):
+    """Two lanes at the 1.7B shapes: the encoder of one request runs while another lane decodes.  Regression for the hazard in
+    DESIGN.md section 4 (a compiler-generated v_pk_fma_f32 with op_sel returned wrong values in lanes 48-63 whenever a wave of
+    another kernel issued MFMAs on the same SIMD; the library is built without packed fp32 instructions since): features
+    and tokens must equal the quiet run bit for bit."""
+    import threading
+    from qwen3_asr_mlx_amd.audio import get_frontend, pack_audio
+    from qwen3_asr_mlx_amd.decoder import set_lane
+    from qwen3_asr_mlx_amd.generate import generate_batch
+    from qwen3_asr_mlx_amd.tokenizer import build_prompt
+    cfg, state, model = full
+    rng = np.random.default_rng(11)
+    durs = np.sort(rng.uniform(8.0, 30.0, 32))[::-1]
+    xs = [signal("speechlike" if i % 2 else "noise", int(d * 16000), seed=500 + i) for i, d in enumerate(durs)]
+    audio, lens_dev, lens = pack_audio(xs, dev)
+    mel, n_frames = get_frontend(dev)(audio, lens_dev, lens)
+    ref, counts = model._encoder.forward_batch(mel, n_frames)
+    ref = ref.clone()
+    lang_ids = model._tokenizer.encode(" English")
+    prompts = [build_prompt(n, lang_ids) for n in counts]
+    N_TOK = 64                                           # decode-dominated: the other lane spends its time in the MFMA decode GEMMs
+    want = generate_batch(model._decoder, ref, counts, prompts, N_TOK, repetition_penalty=1.2)
+    torch.cuda.synchronize()
+    stop, errs, got_tokens = threading.Event(), [], []
+
+    def other_lane():
+        try:
+            set_lane(2)
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                while not stop.is_set():
+                    got_tokens.append(generate_batch(model._decoder, ref, counts, prompts, N_TOK, repetition_penalty=1.2))
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:                        # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=other_lane)
+    th.start()
+    try:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(4)]      # HIP folds streams onto a few hardware queues: make sure
+        for rep in range(24):                                            # some of these do not share the decoding lane's
+            with torch.cuda.stream(streams[rep % 4]):
+                got, _ = model._encoder.forward_batch(mel, n_frames)
+                torch.cuda.current_stream().synchronize()
+                assert torch.equal(got, ref), f"rep {rep}: {int((got != ref).any(dim=1).sum())} feature rows differ beside a decoding lane"
+    finally:
+        stop.set()
+        th.join()
+    assert not errs, errs
+    assert got_tokens and all(t == want for t in got_tokens)
