@@ -156,14 +156,15 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
 def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence[Sequence[int]], max_tokens: Sequence[int],
                         slots: int = 32, temperature: float = 0.0, top_p: float = 1.0, top_k: int = 0,
                         repetition_penalty: float = 1.0, repetition_context_size: int = 100, seed: int = 0,
-                        check_every: int = 16, stats: Optional[dict] = None) -> list[list[int]]:
+                        check_every: int = 16, min_admit: Optional[int] = None, stats: Optional[dict] = None) -> list[list[int]]:
     """Any number of sequences through `slots` decode rows: a row whose sequence has ended (EOS or budget) is handed to the
     next waiting sequence, whose prompt is prefilled into that row of the KV cache while the other rows keep their state
     (the reference decodes one utterance at a time, model.py:239).  `feats[i]`: encoder output
     fp32 [N_i][H] of sequence i.  Sequences are admitted in the order given.  Greedy results equal generate_batch's
     (and the reference loop's) token for token: a row's arithmetic does not depend on its neighbours, its row index or the
     cache capacity.  With temperature > 0 the draws depend on the row a sequence lands in (reproducible, but not equal
-    to a standalone call)."""
+    to a standalone call).  `min_admit`: free rows to wait for before prefilling (one packed prefill of several prompts
+    costs little more than a prefill of one; default rows / 8), ignored once nothing else is running."""
     import torch
     from collections import deque
     n = len(prompts)
@@ -175,6 +176,7 @@ def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence
     if min(mt) < 1:
         raise ValueError("max_tokens must be >= 1")
     B = max(1, min(int(slots), n, 64))
+    min_admit = max(1, B // 8) if min_admit is None else max(1, int(min_admit))
     seq_lens = [len(p) for p in prompts]
     tok_counts = [int(f.shape[0]) for f in feats]
     max_new = max(mt)
@@ -233,10 +235,10 @@ def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence
                     st["row_steps_used"] += n_gen[r]
                     owner[r] = None
             free = [r for r in range(B) if owner[r] is None]
-            if waiting and free:
+            active = [r for r in range(B) if owner[r] is not None]
+            if waiting and free and (len(free) >= min(min_admit, len(waiting)) or not active):
                 admit(free[: len(waiting)])
                 continue                                                   # a budget of 1 ends at the first token
-            active = [r for r in range(B) if owner[r] is not None]
             if not active:
                 break
             # steps until the next look: no further than the first row that must end by budget

@@ -100,6 +100,9 @@ class Qwen3ASR:
         self.lanes = 2              # batches in flight when a request needs more than MAX_BATCH utterances/segments (1: sequential)
         self.continuous = True      # such requests refill decode rows as sequences end (generate_continuous) instead of
                                     # decoding fixed batches to their longest member
+        self.min_admit = None       # free rows to collect before a refill prefill (None: rows / 8)
+        self.continuous_lanes = 1   # lanes in that mode (measured, tools/bench_continuous.py: one lane of 64 refilled rows beats two
+                                    # when token counts cannot be predicted from clip length; two win by 6 % when they can)
 
     @classmethod
     def from_pretrained(cls, model_id_or_path: str | Path, **kwargs) -> "Qwen3ASR":
@@ -281,7 +284,7 @@ class Qwen3ASR:
         from .generate import generate_continuous
         from .tokenizer import build_prompt
         texts: list[str] = [""] * len(jobs)
-        n_lanes = max(1, min(self.lanes, len(jobs) // self.MAX_BATCH))
+        n_lanes = max(1, min(self.continuous_lanes, len(jobs) // self.MAX_BATCH))
         shares = [order[i::n_lanes] for i in range(n_lanes)]
         seeds = [_next_seed() if temperature else 0 for _ in shares]
         lang_ids = self._tokenizer.encode(f" {lang}")
@@ -305,7 +308,7 @@ class Qwen3ASR:
             prompts = [build_prompt(int(f.shape[0]), lang_ids) for f in feats]
             toks = generate_continuous(self._decoder, feats, prompts, [jobs[j][2] for j in sel], self.MAX_BATCH, temperature, top_p,
                                        top_k, repetition_penalty, repetition_context_size, seed=seeds[li],
-                                       stats=self.last_continuous_stats[li])
+                                       min_admit=self.min_admit, stats=self.last_continuous_stats[li])
             for j, t in zip(sel, toks):
                 texts[j] = self._decode_output(t)
 

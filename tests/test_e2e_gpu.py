@@ -246,13 +246,14 @@ def test_continuous_batching_through_the_model_api(dev, small):
         model.MAX_BATCH = 4
         model.continuous = False
         fixed = model._run_jobs(jobs, *args)
-        model.continuous = True
+        model.continuous, model.continuous_lanes = True, 2
         refill = model._run_jobs(jobs, *args)
         assert len(model.last_continuous_stats) == 2 and sum(s["admissions"] for s in model.last_continuous_stats) == len(jobs)
-        model.lanes = 1
+        model.continuous_lanes = 1
         one_lane = model._run_jobs(jobs, *args)
+        assert len(model.last_continuous_stats) == 1
     finally:
-        model.MAX_BATCH, model.lanes, model.continuous = saved, 2, True
+        model.MAX_BATCH, model.continuous, model.continuous_lanes = saved, True, 1
     assert refill == fixed and one_lane == fixed
 
 

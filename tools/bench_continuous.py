@@ -17,6 +17,7 @@ from qwen3_asr_mlx_amd.config import ModelConfig  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 max_batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+workload = sys.argv[3] if len(sys.argv) > 3 else "proportional"     # or "unpredictable": 30 s clips, budgets unrelated to length
 dev = torch.device("cuda:0")
 cfg = ModelConfig()
 state = synth.random_state(cfg, seed=0, device=dev)
@@ -24,11 +25,12 @@ model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
 del state
 model.MAX_BATCH = max_batch
 rng = np.random.default_rng(7)
-durs = rng.uniform(5.0, 30.0, n)
+durs = rng.uniform(5.0, 30.0, n) if workload == "proportional" else rng.uniform(28.0, 30.0, n)
+buds = rng.integers(16, 129, n)
 jobs = []
 for i, d in enumerate(durs):
     x = (0.1 * np.random.default_rng(1234 + i).standard_normal(int(d * 16000))).astype(np.float32)
-    jobs.append((0, x, max(1, int(round(d * 128 / 30)))))
+    jobs.append((0, x, max(1, int(round(d * 128 / 30))) if workload == "proportional" else int(buds[i])))
 audio_s = float(durs.sum())
 args = ("English", 0.0, 1.0, 0, 1.2, 100)
 
@@ -46,18 +48,27 @@ def timed(label, reps=3):
     return {"mode": label, "wall_s": round(best, 4), "rtf": round(audio_s / best, 1)}, texts
 
 
-out = {"clips": n, "audio_s": round(audio_s, 1), "tokens": sum(j[2] for j in jobs), "rows": max_batch}
+out = {"workload": workload, "clips": n, "audio_s": round(audio_s, 1), "tokens": sum(j[2] for j in jobs), "rows": max_batch}
 model.continuous, model.lanes = False, 1
 r0, t0 = timed("fixed batches, one at a time")
 model.lanes = 2
 r1, t1 = timed("fixed batches, two in flight")
 model.continuous, model.lanes = True, 1
-r2, t2 = timed("refilled rows, one lane")
+sweep = []
+for ma in (1, 4, 8, 16, 32):
+    model.min_admit = ma
+    r, t = timed(f"refilled rows, one lane, min_admit {ma}", reps=2)
+    r["texts_equal_fixed"] = t == t0
+    r["steps"] = model.last_continuous_stats[0]["steps"]
+    sweep.append(r)
+best = max(sweep, key=lambda r: r["rtf"])
+model.min_admit = int(best["mode"].rsplit(" ", 1)[1])
+r2, t2 = timed("refilled rows, one lane, best min_admit")
 s2 = [dict(s) for s in model.last_continuous_stats]
-model.lanes = 2
-r3, t3 = timed("refilled rows, two lanes")
+model.continuous_lanes = 2
+r3, t3 = timed("refilled rows, two lanes, best min_admit")
 s3 = [dict(s) for s in model.last_continuous_stats]
-out["runs"] = [r0, r1, r2, r3]
+out["runs"] = [r0, r1] + sweep + [r2, r3]
 out["texts_equal"] = t0 == t1 == t2 == t3
 out["differing"] = {"fixed2_vs_fixed1": sum(a != b for a, b in zip(t0, t1)), "refill1_vs_fixed1": sum(a != b for a, b in zip(t0, t2)),
                     "refill2_vs_fixed1": sum(a != b for a, b in zip(t0, t3)), "first": [i for i, (a, b) in enumerate(zip(t0, t2)) if a != b][:5]}
