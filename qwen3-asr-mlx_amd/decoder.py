@@ -214,7 +214,8 @@ class TextDecoder:
         """Index vectors of one packed prefill.  `slots`: cache rows the sequences go to (default 0..n-1)."""
         slots = tuple(range(len(seq_lens))) if slots is None else slots
         key = (seq_lens, Lmax, slots)
-        pl = self._plans.get(key)
+        plans = self._plans.setdefault(current_lane(), {})   # per lane: eviction frees index tensors another lane could still be reading
+        pl = plans.get(key)
         if pl is None:
             import torch
             cfg, dev = self.config, self.device
@@ -231,9 +232,9 @@ class TextDecoder:
                   "last": i32(last), "M": m, "max_len": max(seq_lens),
                   "kv_off": torch.tensor([b * cfg.num_key_value_heads * Lmax * cfg.head_dim for b in slots],
                                          dtype=torch.int64, device=dev)}
-            if len(self._plans) > 64:
-                self._plans.clear()
-            self._plans[key] = pl
+            if len(plans) > 64:
+                plans.clear()
+            plans[key] = pl
         return pl
 
     def _layers_prefill(self, h, cache: KVCache, seq_lens: Sequence[int], slots: Optional[Sequence[int]] = None):
@@ -299,8 +300,10 @@ class TextDecoder:
         key = (current_lane(), B, max_out)
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) > 16:
-                self._ws.clear()
+            mine = [k for k in self._ws if k[0] == key[0]]
+            if len(mine) > 8:                                # evict this lane's entries only: another lane may be mid-request
+                for k in mine:
+                    del self._ws[k]
             ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device, fp8=getattr(self, "weight_dtype", "bf16") == "fp8")
         return ws
 
@@ -310,8 +313,10 @@ class TextDecoder:
         key = (current_lane(), B, Lmax)
         c = self._caches.get(key)
         if c is None:
-            if len(self._caches) > 4:
-                self._caches.clear()
+            mine = [k for k in self._caches if k[0] == key[0]]
+            if len(mine) > 2:                                # this lane's entries only
+                for k in mine:
+                    del self._caches[k]
             c = self._caches[key] = KVCache()
             c.ensure(self.config, B, Lmax, self.device)
         c.offset = 0

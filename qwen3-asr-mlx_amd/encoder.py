@@ -132,7 +132,11 @@ class AudioEncoder:
 
     # ------------------------------------------------------------------ batch plan (host ints -> device index arrays)
     def _plan(self, n_frames: tuple):
-        plan = self._plans.get(n_frames)
+        # one cache per lane: a plan's index tensors are freed by eviction, and memory freed on one lane's stream must not be
+        # handed out while another lane's launches still read it
+        from .decoder import current_lane
+        plans = self._plans.setdefault(current_lane(), {})
+        plan = plans.get(n_frames)
         if plan is not None:
             return plan
         import torch
@@ -162,9 +166,9 @@ class AudioEncoder:
             "seg_start": i32(seg_start), "seg_len": i32(seg_len), "n_segs": len(seg_len), "max_seg": max(seg_len),
             "kv_off": torch.tensor([s * 3 * self.config.d_model for s in seg_start], dtype=torch.int64, device=dev),
         }
-        if len(self._plans) > 64:
-            self._plans.clear()
-        self._plans[n_frames] = plan
+        if len(plans) > 64:
+            plans.clear()
+        plans[n_frames] = plan
         return plan
 
     # ------------------------------------------------------------------ forward
