@@ -613,3 +613,20 @@ def test_full_size_encoder_bit_identical_beside_decode_on_another_lane(dev, full
         th.join()
     assert not errs, errs
     assert got_tokens and all(t == want for t in got_tokens)
+
+
+def test_continuous_batching_with_sampling_is_reproducible(dev, small):
+    """Refilled rows with temperature / top-k / top-p: budgets respected, ids in range, same seed -> same tokens."""
+    from qwen3_asr_mlx_amd.generate import generate_continuous
+    cfg, state, model = small
+    budgets = [5, 1, 9, 3, 12, 7, 2, 10, 6]
+    xs = [signal("speechlike" if i % 2 else "noise", 16000 + 3000 * (i % 5), seed=700 + i) for i in range(len(budgets))]
+    feats, prompts = _encoded(model, xs, dev)
+    kw = dict(slots=3, temperature=0.8, top_p=0.9, top_k=50, repetition_penalty=1.2, seed=1234, min_admit=1)
+    a = generate_continuous(model._decoder, feats, prompts, budgets, **kw)
+    b = generate_continuous(model._decoder, feats, prompts, budgets, **kw)
+    assert a == b
+    assert [len(t) for t in a] == budgets
+    assert all(0 <= t < cfg.text_decoder.vocab_size for seq in a for t in seq)
+    c = generate_continuous(model._decoder, feats, prompts, budgets, **{**kw, "seed": 99})
+    assert c != a                                        # a different seed draws differently
