@@ -102,6 +102,42 @@ __global__ __launch_bounds__(256) void victim_kernel(float* out, int iters) {
     out[t] = r;
 }
 
+// Same question inside ONE kernel: waves 0-1 of every workgroup run the packed FMA with op_sel, waves 2-3 issue MFMAs
+// (mfma != 0) or idle (mfma == 0).
+__global__ __launch_bounds__(256) void same_kernel_mix(float* out, float* sink, int iters, int mfma) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if ((threadIdx.x >> 6) < 2) {
+        float a = 0.999f - 1e-6f * (t & 1023), b = 0.001f * ((t & 63) + 1);
+        f32x2 pa = {a, a - 1e-4f}, pb = {b, b * 0.5f};
+        f32x2 p[4];
+        for (int i = 0; i < 4; ++i) p[i] = f32x2{0.1f * i, 0.2f * i};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(p[i]) : "v"(pa), "v"(pb));
+        float r = 0.f;
+        for (int i = 0; i < 4; ++i) r += p[i][0] + p[i][1];
+        out[t] = r;
+    } else {
+        out[t] = 0.f;
+        if (!mfma) return;
+        f32x4 acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 a, b;
+        for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (threadIdx.x + e)); b[e] = (__bf16)(0.002f * (threadIdx.x - e)); }
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        float s2 = 0.f;
+        for (int i = 0; i < 8; ++i) s2 += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        if (s2 == 12345.678f) sink[0] = s2;
+    }
+}
+
+extern "C" int same_kernel_launch(float* out, float* sink, int grid, int iters, int mfma, void* stream) {
+    hipLaunchKernelGGL(same_kernel_mix, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, sink, iters, mfma);
+    return (int)hipGetLastError();
+}
+
 extern "C" int victim_launch(int kind, float* out, int grid, int iters, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     switch (kind) {

@@ -66,3 +66,26 @@ for ag in ("mfma",):
         print(f"aggressor {ag:5s} victim {name:30s}: runs wrong {bad_runs}/20, wrong threads {bad_el}, by 16-lane row {rows}", flush=True)
     stop.set()
     th.join()
+
+# ---- the same two instruction streams inside ONE kernel (waves 0-1 packed FMA with op_sel, waves 2-3 MFMA or idle)
+lib.same_kernel_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+fsink = torch.zeros(16, device=dev)
+
+
+def mix(mfma):
+    with torch.cuda.stream(s_main):
+        out.zero_()
+        assert lib.same_kernel_launch(C.c_void_p(out.data_ptr()), C.c_void_p(fsink.data_ptr()), GRID, ITERS, mfma, p_main) == 0
+        r = out.clone()
+    s_main.synchronize()
+    return r
+
+
+quiet = mix(0)
+bad_runs, lanes = 0, torch.zeros(64, dtype=torch.long, device=dev)
+for r in range(20):
+    nz = (mix(1).view(torch.int32) != quiet.view(torch.int32)).nonzero().flatten()
+    bad_runs += nz.numel() > 0
+    lanes += torch.bincount(nz % 64, minlength=64)
+print(f"one kernel, waves 0-1 v_pk_fma_f32 op_sel:[0,1,0] beside its own waves 2-3 issuing MFMAs: runs wrong {bad_runs}/20, "
+      f"by 16-lane row {lanes.view(4, 16).sum(1).tolist()}", flush=True)
