@@ -86,6 +86,11 @@ __global__ __launch_bounds__(256) void victim_kernel(float* out, int iters) {
             if (KIND == 1) asm volatile("v_pk_mul_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %2" : "+v"(p[i]) : "v"(pa), "v"(pb));
             if (KIND == 7) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p[i]) : "v"(pa), "v"(pb));   // src1.lo for both halves
             if (KIND == 8) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(p[i]) : "v"(pa), "v"(pb));      // src1.hi for both halves
+            if (KIND == 9) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(p[i]) : "v"(pa), "v"(pb));      // src0.hi for the low result
+            if (KIND == 10) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,1]" : "+v"(p[i]) : "v"(pa), "v"(pb));     // src2.hi for the low result
+            if (KIND == 11) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel:[0,1]\n\tv_pk_add_f32 %0, %0, %2" : "+v"(p[i]) : "v"(pa), "v"(pb));
+            if (KIND == 12) asm volatile("v_pk_mul_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %2 op_sel:[0,1]" : "+v"(p[i]) : "v"(pa), "v"(pb));
+            if (KIND == 13) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(p[i]) : "v"(pa), "v"(pb));   // src1 halves swapped
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -150,6 +155,11 @@ extern "C" int victim_launch(int kind, float* out, int grid, int iters, void* st
         case 6: hipLaunchKernelGGL(victim_kernel<6>, dim3(grid), dim3(256), 0, s, out, iters); break;
         case 7: hipLaunchKernelGGL(victim_kernel<7>, dim3(grid), dim3(256), 0, s, out, iters); break;
         case 8: hipLaunchKernelGGL(victim_kernel<8>, dim3(grid), dim3(256), 0, s, out, iters); break;
+        case 13: hipLaunchKernelGGL(victim_kernel<13>, dim3(grid), dim3(256), 0, s, out, iters); break;
+        case 12: hipLaunchKernelGGL(victim_kernel<12>, dim3(grid), dim3(256), 0, s, out, iters); break;
+        case 11: hipLaunchKernelGGL(victim_kernel<11>, dim3(grid), dim3(256), 0, s, out, iters); break;
+        case 10: hipLaunchKernelGGL(victim_kernel<10>, dim3(grid), dim3(256), 0, s, out, iters); break;
+        case 9: hipLaunchKernelGGL(victim_kernel<9>, dim3(grid), dim3(256), 0, s, out, iters); break;
         default: return -1;
     }
     return (int)hipGetLastError();

@@ -25,7 +25,9 @@ sink = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
 s_main, s_load = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 p_main, p_load = C.c_void_p(s_main.cuda_stream), C.c_void_p(s_load.cuda_stream)
 torch.cuda.synchronize()
-NAMES = ["v_pk_fma_f32", "v_pk_mul_f32 + v_pk_add_f32", "v_fma_f32", "v_fmaak_f32", "v_exp_f32", "v_rcp_f32", "v_mul_f32 + v_add_f32", "v_pk_fma_f32 op_sel_hi:[1,0,1]", "v_pk_fma_f32 op_sel:[0,1,0]"]
+NAMES = ["v_pk_fma_f32", "v_pk_mul_f32 + v_pk_add_f32", "v_fma_f32", "v_fmaak_f32", "v_exp_f32", "v_rcp_f32", "v_mul_f32 + v_add_f32", "v_pk_fma_f32 op_sel_hi:[1,0,1]", "v_pk_fma_f32 op_sel:[0,1,0]",
+         "v_pk_fma_f32 op_sel:[1,0,0]", "v_pk_fma_f32 op_sel:[0,0,1]", "v_pk_mul_f32 op_sel:[0,1] + v_pk_add_f32", "v_pk_mul_f32 + v_pk_add_f32 op_sel:[0,1]",
+         "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1]"]
 AGGR = {"mfma": (1, 20000), "valu": (2, 50000)}
 stop = threading.Event()
 
@@ -63,7 +65,7 @@ for ag in ("mfma",):
             bad_el += nz.numel()
             lanes += torch.bincount(nz % 64, minlength=64)
         rows = lanes.view(4, 16).sum(1).tolist()
-        print(f"aggressor {ag:5s} victim {name:30s}: runs wrong {bad_runs}/20, wrong threads {bad_el}, by 16-lane row {rows}", flush=True)
+        print(f"aggressor {ag:5s} victim {name:42s}: runs wrong {bad_runs}/20, wrong threads {bad_el}, by 16-lane row {rows}", flush=True)
     stop.set()
     th.join()
 
