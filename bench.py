@@ -103,8 +103,8 @@ def cpu_baseline(cfg, state, clip, n_dec_sample: int, n_dec_full: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps (BASELINE.json protocol: >= 20 repeats after 3 warm-ups)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--clip-seconds", type=float, default=30.0)
     ap.add_argument("--ndec", type=int, default=128, help="decoded tokens per utterance")
@@ -265,7 +265,7 @@ def main() -> None:
         # that keeps the GPU fed, with the per-batch latency it costs.
         import threading
         from qwen3_asr_mlx_amd.decoder import set_lane
-        n_each, lat2, errs = 3, [], []
+        n_each, lat2, errs = 8, [], []                 # per lane: enough batches that the ramp at both ends stays small
         gate = threading.Barrier(args.inflight + 1)
 
         def worker(lane):
