@@ -355,7 +355,10 @@ extern "C" int q3asr_skinny3_gemm_norm(const float* in_slab, int in_n_slabs, int
 // (decoder.py:191,194 / :196,189 / :251).  One workgroup per row; a thread owns 8 consecutive
 // columns = one X16 fragment (one 16-byte store).
 // ---------------------------------------------------------------------------
-template <int EPT>   // N = 256 * EPT, EPT in {2,4,8,16} (EPT < 8: N = 512/1024 handled with 8-wide threads, fewer active)
+// SS > 0: the slab count is known at compile time -- every load of the thread (SS slab pieces, its residual and norm-weight
+// vectors) is issued before the first add, one memory round trip instead of one per pair of slabs plus two more; the sum
+// runs in the same order (slab 0, 1, 2, ...), so results are bit-identical to the SS = 0 loop.
+template <int EPT, int SS = 0>   // N = 256 * EPT, EPT in {2,4,8,16} (EPT < 8: N = 512/1024 handled with 8-wide threads, fewer active)
 __global__ __launch_bounds__(256) void slab_resnorm_x16_kernel(const float* __restrict__ slab, int S, long slab_stride,
                                                                const bf16* __restrict__ h_in, bf16* __restrict__ h_out,
                                                                const bf16* __restrict__ w, bf16* __restrict__ x16, int MT,
@@ -366,12 +369,28 @@ __global__ __launch_bounds__(256) void slab_resnorm_x16_kernel(const float* __re
     const int m = blockIdx.x;
     float q2 = 0.f;
     float hv[(NV + 255) / 256][8];
+    bf16x8 wpre[(NV + 255) / 256];
+    bf16x8 hpre;
 #pragma unroll
     for (int it = 0; it < (NV + 255) / 256; ++it) {
         const int v = threadIdx.x + 256 * it;
         if (v < NV) {
             const long c0 = (long)m * N + 8 * v;
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(slab + c0), a1 = *reinterpret_cast<const f32x4*>(slab + c0 + 4);
+            f32x4 a0, a1;
+            if constexpr (SS > 0) {
+                f32x4 p0[SS], p1[SS];
+#pragma unroll
+                for (int q = 0; q < SS; ++q) {
+                    p0[q] = *reinterpret_cast<const f32x4*>(slab + q * slab_stride + c0);
+                    p1[q] = *reinterpret_cast<const f32x4*>(slab + q * slab_stride + c0 + 4);
+                }
+                wpre[it] = *reinterpret_cast<const bf16x8*>(w + 8 * v);
+                hpre = *reinterpret_cast<const bf16x8*>(h_in + c0);
+                a0 = p0[0]; a1 = p1[0];
+#pragma unroll
+                for (int q = 1; q < SS; ++q) { a0 += p0[q]; a1 += p1[q]; }
+            } else {
+            a0 = *reinterpret_cast<const f32x4*>(slab + c0); a1 = *reinterpret_cast<const f32x4*>(slab + c0 + 4);
             int s = 1;
             for (; s + 1 < S; s += 2) {                    // two slabs per trip: independent loads in flight
                 const float* p = slab + s * slab_stride + c0;
@@ -384,7 +403,9 @@ __global__ __launch_bounds__(256) void slab_resnorm_x16_kernel(const float* __re
                 a0 += *reinterpret_cast<const f32x4*>(p);
                 a1 += *reinterpret_cast<const f32x4*>(p + 4);
             }
-            const bf16x8 hi = *reinterpret_cast<const bf16x8*>(h_in + c0);
+            hpre = *reinterpret_cast<const bf16x8*>(h_in + c0);
+            }
+            const bf16x8 hi = hpre;
             bf16x8 ho;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -404,7 +425,9 @@ __global__ __launch_bounds__(256) void slab_resnorm_x16_kernel(const float* __re
     for (int it = 0; it < (NV + 255) / 256; ++it) {
         const int v = threadIdx.x + 256 * it;
         if (v < NV) {
-            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + 8 * v);
+            bf16x8 wv;
+            if constexpr (SS > 0) wv = wpre[it];
+            else wv = *reinterpret_cast<const bf16x8*>(w + 8 * v);
             bf16x8 xo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) xo[e] = f2bf(hv[it][e] * r * bf2f(wv[e]));
@@ -424,7 +447,12 @@ extern "C" int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t sl
     switch (N / 256) {
         case 2: hipLaunchKernelGGL(slab_resnorm_x16_kernel<2>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps); break;
         case 4: hipLaunchKernelGGL(slab_resnorm_x16_kernel<4>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps); break;
-        case 8: hipLaunchKernelGGL(slab_resnorm_x16_kernel<8>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps); break;
+        case 8:                                                       // hidden size 2048: the decode step's shape
+            if (n_slabs == 4) hipLaunchKernelGGL((slab_resnorm_x16_kernel<8, 4>), grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps);
+            else if (n_slabs == 8) hipLaunchKernelGGL((slab_resnorm_x16_kernel<8, 8>), grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps);
+            else if (n_slabs == 2) hipLaunchKernelGGL((slab_resnorm_x16_kernel<8, 2>), grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps);
+            else hipLaunchKernelGGL(slab_resnorm_x16_kernel<8>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps);
+            break;
         default: hipLaunchKernelGGL(slab_resnorm_x16_kernel<16>, grid, blk, 0, s, slab, n_slabs, (long)slab_stride, hi, ho, ww, xo, MT, eps); break;
     }
     return q3_check_launch("slab_resnorm_x16");

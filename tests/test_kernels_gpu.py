@@ -770,3 +770,33 @@ def test_skinny3_fp8_weights(dev, M, N, K, S, waves, rt, ksplit, epi):
         r = ref.reshape(M, I // 16, 2, 16)
         g, u = bfr(r[:, :, 0].reshape(M, I)), bfr(r[:, :, 1].reshape(M, I))
         torch.testing.assert_close(ops.from_x16(o16, M).float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=2e-2, rtol=1.6e-2)
+
+
+@pytest.mark.parametrize("M,S", [(32, 2), (32, 4), (32, 8), (7, 3), (64, 8), (1, 4)])
+def test_slab_resnorm_slab_count_specialisations_sum_in_slab_order(dev, M, S):
+    """Hidden size 2048 with 2 / 4 / 8 slabs runs a fully unrolled specialisation (all loads first); like the generic loop
+    (S = 3 here) it must add the slabs in index order: the residual stream equals the sequential fp32 sum exactly, and the
+    specialised and generic forms agree bit for bit on the same values (a zero slab appended to S = 3 gives S = 4)."""
+    from qwen3_asr_mlx_amd import ops
+    N = 2048
+    slab = rnd((S, M, N), dev, 220 + S, 0.5, torch.float32)
+    h = rnd((M, N), dev, 231)
+    w = rnd((N,), dev, 232) + 1
+    MT = ops.mt_of(M)
+
+    def run(sl, n):
+        ho = torch.empty_like(h)
+        x16 = torch.zeros((N // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.call("q3asr_slab_resnorm_x16", ops.ptr(sl), n, M * N, ops.ptr(h), ops.ptr(ho), ops.ptr(w), ops.ptr(x16), M, N, 1e-6, ops.sp())
+        return ho, x16
+
+    ho, x16 = run(slab, S)
+    tot = slab[0].clone()
+    for s_ in range(1, S):
+        tot = tot + slab[s_]
+    href = (tot.to(torch.bfloat16).float() + h.float()).to(torch.bfloat16)
+    assert torch.equal(ho, href)
+    if S == 3:
+        padded = torch.cat([slab, torch.zeros_like(slab[:1])])               # + 0.0 changes nothing (no -0.0 sums here)
+        ho4, x4 = run(padded, 4)
+        assert torch.equal(ho4, ho) and torch.equal(x4, x16)
