@@ -24,4 +24,7 @@ for _mod, _names in _PUBLIC:
         globals()[_n] = getattr(_mod, _n)
         __all__.append(_n)
 generate_batch = _generate.generate_batch          # batch API (new; not part of the reference surface)
+generate_continuous = _generate.generate_continuous
+from . import serve  # noqa: E402
+ContinuousTranscriber = serve.ContinuousTranscriber   # queue front door over refilled decode rows (new)
 del _mod, _names, _n

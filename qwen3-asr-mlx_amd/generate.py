@@ -153,6 +153,129 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
     return (out, ws, cache) if return_state else out
 
 
+class RowScheduler:
+    """`rows` decode rows over one KV cache and one captured decode step; sequences are admitted into free rows (their prompts
+    packed into one prefill that writes only those rows) and harvested when they end.  The building block of
+    generate_continuous (a fixed list of sequences) and of serve.ContinuousTranscriber (a live queue).  All device work
+    runs on the lane's side stream; call it from one thread."""
+
+    def __init__(self, decoder: TextDecoder, rows: int, max_prompt: int, max_new: int, sampling: dict, check_every: int = 16):
+        import torch
+        self.dec, self.B = decoder, int(rows)
+        if not 1 <= self.B <= 64:
+            raise ValueError("RowScheduler handles 1..64 rows")
+        self.max_prompt, self.max_new, self.check_every = int(max_prompt), int(max_new), int(check_every)
+        self.Lmax = (self.max_prompt + self.max_new + 63) // 64 * 64
+        self.cache = decoder.batch_cache(self.B, self.Lmax)
+        self.ws = decoder.workspace(self.B, self.max_new)
+        self.dev = decoder.device
+        self.sampling = dict(sampling)
+        self.owner: list = [None] * self.B           # key of the sequence in each row
+        self.budget: list = [0] * self.B
+        self.admit_logits = torch.empty((self.B, decoder.config.vocab_size), dtype=torch.bfloat16, device=self.dev)
+        self.captured = False
+        self.stats = {"steps": 0, "admissions": 0, "checks": 0, "row_steps_used": 0, "rows": self.B}
+        self.side = _side_stream(self.dev)
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.ws.finished.fill_(1)                # rows without a sequence stay inert
+            self.ws.n_gen.zero_()
+        self._fin = [1] * self.B
+        self._ngen = [0] * self.B
+        self._fresh = True                           # host copies of finished / n_gen match the device
+
+    def free_rows(self) -> list:
+        return [r for r in range(self.B) if self.owner[r] is None]
+
+    def active(self) -> int:
+        return sum(o is not None for o in self.owner)
+
+    def admit(self, items: Sequence) -> None:
+        """items: (key, feats fp32 [N][H], prompt ids, max_tokens) -- at most as many as there are free rows.  Prefill, reset
+        the rows' counters, draw each first token (generate.py:278-286)."""
+        import torch
+        rows = self.free_rows()[: len(items)]
+        if len(rows) < len(items):
+            raise ValueError(f"admit: {len(items)} sequences for {len(rows)} free rows")
+        dec, ws = self.dec, self.ws
+        seq_lens = [len(it[2]) for it in items]
+        counts = [int(it[1].shape[0]) for it in items]
+        budgets = [int(it[3]) for it in items]
+        if max(seq_lens) > self.max_prompt or max(budgets) > self.max_new or min(budgets) < 1:
+            raise ValueError(f"admit: prompt of {max(seq_lens)} tokens / budget {max(budgets)} exceeds this scheduler's {self.max_prompt} / {self.max_new}")
+        self.side.wait_stream(torch.cuda.current_stream())       # the features were produced on the caller's stream
+        with torch.cuda.stream(self.side):
+            packed = torch.cat([torch.as_tensor(it[1]).to(self.dev, torch.float32).reshape(c, -1) for it, c in zip(items, counts)])
+            embeds = _merge(packed, [it[2] for it in items], counts, dec)
+            full = rows == list(range(self.B))
+            logits = ws.logits if full else self.admit_logits
+            dec.prefill(embeds, seq_lens, self.cache, logits_out=logits, slots=None if full else rows)
+            idx = torch.tensor(rows, dtype=torch.long, device=self.dev)
+            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=self.dev)      # noqa: E731
+            ws.n_gen.index_fill_(0, idx, 0)
+            ws.finished.index_fill_(0, idx, 0)
+            ws.pos.index_copy_(0, idx, i32([t - 1 for t in seq_lens]))
+            ws.max_new.index_copy_(0, idx, i32(budgets))
+            if full:
+                dec.sample_step(ws, ws.logits, self.sampling)
+            else:
+                for j, r in enumerate(rows):
+                    dec.sample_rows(ws, logits[j], r, self.sampling)
+        for r, it, b in zip(rows, items, budgets):
+            self.owner[r], self.budget[r] = it[0], b
+        self.stats["admissions"] += len(items)
+        self._fresh = False
+
+    def _look(self) -> None:
+        import torch
+        if not self._fresh:
+            with torch.cuda.stream(self.side):
+                self._fin, self._ngen = self.ws.finished.tolist(), self.ws.n_gen.tolist()       # synchronises the side stream
+            self.stats["checks"] += 1
+            self._fresh = True
+
+    def harvest(self) -> list:
+        """[(key, token ids)] of the sequences that have ended (EOS or budget); their rows become free."""
+        import torch
+        self._look()
+        ended = [r for r in range(self.B) if self.owner[r] is not None and self._fin[r]]
+        if not ended:
+            return []
+        with torch.cuda.stream(self.side):
+            toks = self.ws.out_tokens[torch.tensor(ended, dtype=torch.long, device=self.dev)].cpu()
+        out = []
+        for j, r in enumerate(ended):
+            out.append((self.owner[r], toks[j, : self._ngen[r]].tolist()))
+            self.stats["row_steps_used"] += self._ngen[r]
+            self.owner[r] = None
+        return out
+
+    def run(self) -> int:
+        """Decode until the next look: check_every steps, or fewer if a row must end by budget before that."""
+        import torch
+        self._look()
+        act = [r for r in range(self.B) if self.owner[r] is not None and not self._fin[r]]
+        if not act:
+            return 0
+        k = max(1, min(self.check_every, min(self.budget[r] - self._ngen[r] for r in act)))
+        done = 0
+        with torch.cuda.stream(self.side):
+            if not self.captured:
+                self.dec.decode_step(self.ws, self.cache, self.sampling)        # eager: loads code objects, a real step
+                self.dec.capture_step(self.ws, self.cache, self.sampling)
+                self.captured = True
+                done = 1
+            while done < k:
+                done += self.dec.replay_step(self.ws, multi=k - done >= self.dec.MULTI_STEPS)
+        self.stats["steps"] += done
+        self._fresh = False
+        return done
+
+    def finish(self) -> None:
+        import torch
+        torch.cuda.current_stream().wait_stream(self.side)
+
+
 def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence[Sequence[int]], max_tokens: Sequence[int],
                         slots: int = 32, temperature: float = 0.0, top_p: float = 1.0, top_k: int = 0,
                         repetition_penalty: float = 1.0, repetition_context_size: int = 100, seed: int = 0,
@@ -165,7 +288,6 @@ def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence
     cache capacity.  With temperature > 0 the draws depend on the row a sequence lands in (reproducible, but not equal
     to a standalone call).  `min_admit`: free rows to wait for before prefilling (one packed prefill of several prompts
     costs little more than a prefill of one; default rows / 8), ignored once nothing else is running."""
-    import torch
     from collections import deque
     n = len(prompts)
     if n == 0:
@@ -177,85 +299,26 @@ def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence
         raise ValueError("max_tokens must be >= 1")
     B = max(1, min(int(slots), n, 64))
     min_admit = max(1, B // 8) if min_admit is None else max(1, int(min_admit))
-    seq_lens = [len(p) for p in prompts]
-    tok_counts = [int(f.shape[0]) for f in feats]
-    max_new = max(mt)
-    Lmax = (max(t + m for t, m in zip(seq_lens, mt)) + 63) // 64 * 64
-    cache = decoder.batch_cache(B, Lmax)
-    ws = decoder.workspace(B, max_new)
-    dev = decoder.device
-    V = decoder.config.vocab_size
     sampling = {"temperature": float(temperature), "top_p": float(top_p), "top_k": int(top_k),
                 "repetition_penalty": float(repetition_penalty),
                 "repetition_context_size": int(repetition_context_size), "seed": int(seed)}
+    sch = RowScheduler(decoder, B, max(len(p) for p in prompts), max(mt), sampling, check_every)
     waiting = deque(range(n))
-    owner: list = [None] * B                     # sequence in each row
     out: list = [None] * n
-    admit_logits = torch.empty((B, V), dtype=torch.bfloat16, device=dev)
-    st = {"steps": 0, "admissions": 0, "checks": 0, "row_steps_used": 0}
-
-    def admit(rows: list) -> None:
-        """Prefill the next waiting sequences into `rows`, reset those rows' counters, draw their first token."""
-        seqs = [waiting.popleft() for _ in rows]
-        for r, u in zip(rows, seqs):
-            owner[r] = u
-        packed = torch.cat([torch.as_tensor(feats[u]).to(dev, torch.float32).reshape(tok_counts[u], -1) for u in seqs])
-        embeds = _merge(packed, [prompts[u] for u in seqs], [tok_counts[u] for u in seqs], decoder)
-        full = len(rows) == B and rows == list(range(B))
-        logits = ws.logits if full else admit_logits
-        decoder.prefill(embeds, [seq_lens[u] for u in seqs], cache, logits_out=logits, slots=None if full else rows)
-        idx = torch.tensor(rows, dtype=torch.long, device=dev)
-        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
-        ws.n_gen.index_fill_(0, idx, 0)
-        ws.finished.index_fill_(0, idx, 0)
-        ws.pos.index_copy_(0, idx, i32([seq_lens[u] - 1 for u in seqs]))
-        ws.max_new.index_copy_(0, idx, i32([mt[u] for u in seqs]))
-        if full:
-            decoder.sample_step(ws, ws.logits, sampling)
-        else:
-            for j, r in enumerate(rows):                                    # first token (generate.py:278-286), this row only
-                decoder.sample_rows(ws, logits[j], r, sampling)
-        st["admissions"] += len(rows)
-
-    side = _side_stream(dev)
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        ws.finished.fill_(1)                     # rows without a sequence stay inert
-        ws.n_gen.zero_()
-        admit(list(range(B)))
-        captured = False
-        while True:
-            fin, n_gen = ws.finished.tolist(), ws.n_gen.tolist()           # synchronises `side`
-            st["checks"] += 1
-            ended = [r for r in range(B) if owner[r] is not None and fin[r]]
-            if ended:
-                toks = ws.out_tokens[torch.tensor(ended, dtype=torch.long, device=dev)].cpu()
-                for j, r in enumerate(ended):
-                    out[owner[r]] = toks[j, : n_gen[r]].tolist()
-                    st["row_steps_used"] += n_gen[r]
-                    owner[r] = None
-            free = [r for r in range(B) if owner[r] is None]
-            active = [r for r in range(B) if owner[r] is not None]
-            if waiting and free and (len(free) >= min(min_admit, len(waiting)) or not active):
-                admit(free[: len(waiting)])
-                continue                                                   # a budget of 1 ends at the first token
-            if not active:
-                break
-            # steps until the next look: no further than the first row that must end by budget
-            k = max(1, min(check_every, min(mt[owner[r]] - n_gen[r] for r in active)))
-            if not captured:
-                decoder.decode_step(ws, cache, sampling)                   # eager: loads code objects, a real step
-                decoder.capture_step(ws, cache, sampling)
-                captured = True
-                k -= 1
-                st["steps"] += 1
-            while k > 0:
-                d = decoder.replay_step(ws, multi=k >= decoder.MULTI_STEPS)
-                k -= d
-                st["steps"] += d
-    torch.cuda.current_stream().wait_stream(side)
+    while True:
+        for key, toks in sch.harvest():
+            out[key] = toks
+        free = sch.free_rows()
+        if waiting and free and (len(free) >= min(min_admit, len(waiting)) or not sch.active()):
+            take = [waiting.popleft() for _ in range(min(len(free), len(waiting)))]
+            sch.admit([(u, feats[u], prompts[u], mt[u]) for u in take])
+            continue                                                       # a budget of 1 ends at the first token
+        if not sch.active():
+            break
+        sch.run()
+    sch.finish()
     if stats is not None:
-        stats.update(st, rows=B)
+        stats.update(sch.stats)
     return out
 
 

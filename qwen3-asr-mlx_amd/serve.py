@@ -1,0 +1,182 @@
+"""A queue in front of the decode rows ("streaming front door"): requests arrive at any time from
+any thread, a worker thread encodes what has arrived, admits it into free rows of a running RowScheduler and resolves each
+request's future when its sequence (or, for long audio, all of its segments) has ended.  The reference serialises whole
+`transcribe()` calls behind one lock (model.py:239); results here equal `transcribe()` of the same audio and options.
+
+One ContinuousTranscriber = one lane of the decoder (its own decode workspace, KV cache, captured step and streams) and one
+set of sampling options (they are baked into the captured decode step)."""
+from __future__ import annotations
+
+import queue
+import threading
+from collections import deque
+from concurrent.futures import Future
+from typing import Optional
+
+import numpy as np
+
+from .audio import get_frontend, pack_audio
+from .generate import RowScheduler
+from .model import Qwen3ASR, TranscriptionResult, plan_jobs
+from .tokenizer import build_prompt
+
+_STOP = object()
+
+
+class ContinuousTranscriber:
+    def __init__(self, model: Qwen3ASR, rows: int = 32, language: Optional[str] = None, temperature: float = 0.0, top_p: float = 1.0,
+                 top_k: int = 0, repetition_penalty: float = 1.2, repetition_context_size: int = 100, seed: int = 0,
+                 chunk_duration: float = 30.0, max_new_tokens: int = 1750, lane: int = 7, check_every: int = 16,
+                 min_admit: Optional[int] = None, max_wait_rows: int = 64) -> None:
+        """`chunk_duration`: audio longer than this is split at low-energy points (as transcribe() does at 1200 s) so that every
+        sequence fits the row capacity, which is sized for chunk_duration + 5 s of audio and `max_new_tokens` new tokens.
+        `lane`: decoder lane of the worker thread (keep it different from lanes used elsewhere in the process)."""
+        self.model = model
+        self.rows = int(rows)
+        self.lang = model._resolve_language(language)
+        self.sampling = {"temperature": float(temperature), "top_p": float(top_p), "top_k": int(top_k),
+                         "repetition_penalty": float(repetition_penalty),
+                         "repetition_context_size": int(repetition_context_size), "seed": int(seed)}
+        self.chunk_duration = float(chunk_duration)
+        self.max_new = int(max_new_tokens)
+        self.lane, self.check_every, self.min_admit = int(lane), int(check_every), min_admit
+        self.max_wait_rows = int(max_wait_rows)
+        enc = model._encoder
+        frames = int((self.chunk_duration + 5.0) * 100) + 1
+        n_audio = (frames // enc.chunk_size) * enc.tokens_per_chunk + (enc._conv_output_length(frames % enc.chunk_size) if frames % enc.chunk_size else 0)
+        self._lang_ids = model._tokenizer.encode(f" {self.lang}")
+        self.max_prompt = len(build_prompt(n_audio, self._lang_ids))
+        self._q: "queue.Queue" = queue.Queue()
+        self._closed = False
+        self.stats: dict = {}
+        self._err: Optional[BaseException] = None
+        self._th = threading.Thread(target=self._loop, name="q3asr-rows", daemon=True)
+        self._th.start()
+
+    # ------------------------------------------------------------------ client side
+    def submit(self, audio, max_tokens: Optional[int] = None) -> Future:
+        """Queue one utterance (path or 1-D float array, as transcribe()).  The future resolves to a TranscriptionResult."""
+        if self._closed:
+            raise RuntimeError("ContinuousTranscriber is closed")
+        fut: Future = Future()
+        samples = self.model._as_samples(audio)
+        if len(samples) == 0:
+            fut.set_result(TranscriptionResult(text="", language="Unknown", duration=0.0))
+            return fut
+        jobs, _ = plan_jobs([samples], self.chunk_duration, max_tokens)
+        if any(j[2] > self.max_new for j in jobs):
+            raise ValueError(f"max_tokens {max(j[2] for j in jobs)} exceeds this transcriber's max_new_tokens={self.max_new}")
+        req = {"future": fut, "texts": [None] * len(jobs), "left": len(jobs), "duration": len(samples) / 16_000,
+               "joined": len(samples) / 16_000 > self.chunk_duration}
+        self._q.put([(req, k, j[1], int(j[2])) for k, j in enumerate(jobs)])
+        return fut
+
+    def transcribe(self, audio, max_tokens: Optional[int] = None) -> TranscriptionResult:
+        return self.submit(audio, max_tokens).result()
+
+    def close(self) -> None:
+        """Finish what has been submitted, then stop the worker."""
+        if not self._closed:
+            self._closed = True
+            self._q.put(_STOP)
+            self._th.join()
+        if self._err is not None:
+            raise self._err
+
+    def __enter__(self) -> "ContinuousTranscriber":
+        return self
+
+    def __exit__(self, *args) -> None:
+        self.close()
+
+    # ------------------------------------------------------------------ worker
+    def _drain(self, block: bool):
+        """Segments that have arrived: [(req, k, samples, budget)], and whether the stop marker was seen."""
+        items, stop = [], False
+        try:
+            got = self._q.get(timeout=0.05) if block else self._q.get_nowait()
+            while True:
+                if got is _STOP:
+                    stop = True
+                else:
+                    items += got
+                if len(items) >= self.max_wait_rows:
+                    break
+                got = self._q.get_nowait()
+        except queue.Empty:
+            pass
+        return items, stop
+
+    def _encode(self, segs: list) -> list:
+        """mel + encoder for the arrived segments (batches of <= MAX_BATCH, longest first); returns scheduler items."""
+        model, dev = self.model, self.model._decoder.device
+        out = []
+        order = sorted(range(len(segs)), key=lambda i: -len(segs[i][2]))
+        for s0 in range(0, len(order), model.MAX_BATCH):
+            part = [segs[i] for i in order[s0: s0 + model.MAX_BATCH]]
+            audio, lens_dev, lens = pack_audio([p[2] for p in part], dev)
+            mel, n_frames = get_frontend(dev)(audio, lens_dev, lens)
+            packed, counts = model._encoder.forward_batch(mel, n_frames)
+            o = 0
+            for p, c in zip(part, counts):
+                out.append(((p[0], p[1]), packed[o: o + c], build_prompt(int(c), self._lang_ids), p[3]))
+                o += c
+        return out
+
+    def _resolve(self, key, tokens: list) -> None:
+        req, k = key
+        req["texts"][k] = self.model._decode_output(tokens)
+        req["left"] -= 1
+        if req["left"] == 0:
+            text = " ".join(t for t in req["texts"] if t) if req["joined"] else req["texts"][0]
+            req["future"].set_result(TranscriptionResult(text=text, language=self.lang, duration=req["duration"]))
+
+    def _loop(self) -> None:
+        import torch
+        from .decoder import set_lane
+        dev = self.model._decoder.device
+        inflight: dict = {}                                  # (id(request), segment) -> key, for failing futures on error
+        try:
+            set_lane(self.lane)
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                sch = RowScheduler(self.model._decoder, self.rows, self.max_prompt, self.max_new, self.sampling, self.check_every)
+                min_admit = max(1, self.rows // 8) if self.min_admit is None else max(1, int(self.min_admit))
+                pending: deque = deque()
+                stopping = False
+                while True:
+                    idle = not sch.active() and not pending
+                    if idle and stopping:
+                        break
+                    segs, stop = self._drain(block=idle and not stopping)
+                    stopping = stopping or stop
+                    if segs:
+                        items = self._encode(segs)
+                        inflight.update({(id(it[0][0]), it[0][1]): it[0] for it in items})
+                        pending.extend(items)
+                    for key, toks in sch.harvest():
+                        self._resolve(key, toks)
+                        inflight.pop((id(key[0]), key[1]), None)
+                    free = sch.free_rows()
+                    # rows freed one at a time wait for company (a packed prefill of 4 costs little more than one of 1), unless
+                    # nothing else is running or nothing more can arrive
+                    if pending and free and (len(free) >= min(min_admit, len(pending)) or not sch.active()):
+                        sch.admit([pending.popleft() for _ in range(min(len(free), len(pending)))])
+                        continue
+                    sch.run()
+                sch.finish()
+                torch.cuda.current_stream().synchronize()
+                self.stats = dict(sch.stats)
+        except BaseException as e:                            # noqa: BLE001
+            self._err = e
+            for key in inflight.values():
+                if not key[0]["future"].done():
+                    key[0]["future"].set_exception(e)
+            while True:                                       # fail what is still queued
+                try:
+                    got = self._q.get_nowait()
+                except queue.Empty:
+                    break
+                if got is not _STOP:
+                    for seg in got:
+                        if not seg[0]["future"].done():
+                            seg[0]["future"].set_exception(e)

@@ -630,3 +630,40 @@ def test_continuous_batching_with_sampling_is_reproducible(dev, small):
     assert all(0 <= t < cfg.text_decoder.vocab_size for seq in a for t in seq)
     c = generate_continuous(model._decoder, feats, prompts, budgets, **{**kw, "seed": 99})
     assert c != a                                        # a different seed draws differently
+
+
+def test_queue_front_door_equals_transcribe(dev, small):
+    """serve.ContinuousTranscriber: requests submitted from several threads at different times, ragged budgets, one clip long
+    enough to be split into segments; every future resolves to what transcribe() returns for the same audio and options."""
+    import threading
+    import time
+    from qwen3_asr_mlx_amd.serve import ContinuousTranscriber
+    cfg, state, model = small
+    xs = [signal("speechlike" if i % 2 else "noise", 16000 + 2100 * (i % 6), seed=800 + i) for i in range(14)]
+    budgets = [3 + (5 * i) % 11 for i in range(len(xs))]
+    long_clip = signal("speechlike", 16000 * 5 + 333, seed=850)
+    want = [model.transcribe(x, max_tokens=m).text for x, m in zip(xs, budgets)]
+    want_long = model.transcribe(long_clip, chunk_duration=2.0)            # segments decode with their own budgets (>= 256)
+    futs: dict = {}
+    with ContinuousTranscriber(model, rows=4, chunk_duration=2.0, max_new_tokens=400, min_admit=1, check_every=4) as srv:
+        def client(ids, delay):
+            for i in ids:
+                time.sleep(delay)
+                futs[i] = srv.submit(xs[i], max_tokens=budgets[i])
+        ths = [threading.Thread(target=client, args=(range(k, len(xs), 3), 0.002 * (k + 1))) for k in range(3)]
+        for th in ths:
+            th.start()
+        fl = srv.submit(long_clip)
+        empty = srv.submit(np.zeros(0, dtype=np.float32))
+        for th in ths:
+            th.join()
+        got = [futs[i].result(timeout=120).text for i in range(len(xs))]
+        res_long = fl.result(timeout=120)
+        assert empty.result(timeout=5).text == ""
+        with pytest.raises(ValueError):
+            srv.submit(xs[0], max_tokens=401)
+    assert got == want
+    assert res_long.text == want_long.text and res_long.duration == want_long.duration and res_long.language == "English"
+    assert srv.stats["admissions"] >= len(xs) + 2 and srv.stats["rows"] == 4
+    with pytest.raises(RuntimeError):
+        srv.submit(xs[0])
