@@ -27,10 +27,12 @@ class ContinuousTranscriber:
     def __init__(self, model: Qwen3ASR, rows: int = 32, language: Optional[str] = None, temperature: float = 0.0, top_p: float = 1.0,
                  top_k: int = 0, repetition_penalty: float = 1.2, repetition_context_size: int = 100, seed: int = 0,
                  chunk_duration: float = 30.0, max_new_tokens: int = 1750, lane: int = 7, check_every: int = 16,
-                 min_admit: Optional[int] = None, max_wait_rows: int = 64) -> None:
+                 min_admit: Optional[int] = None, max_wait_rows: int = 64, encode_thread: bool = True) -> None:
         """`chunk_duration`: audio longer than this is split at low-energy points (as transcribe() does at 1200 s) so that every
         sequence fits the row capacity, which is sized for chunk_duration + 5 s of audio and `max_new_tokens` new tokens.
-        `lane`: decoder lane of the worker thread (keep it different from lanes used elsewhere in the process)."""
+        `lane`: decoder lane of the worker thread (keep it different from lanes used elsewhere in the process).
+        `encode_thread`: mel + encoder of arriving audio run on a second thread and stream (lane + 1), beside the decode rows
+        (MFMA-bound work beside latency-bound work) instead of between decode chunks."""
         self.model = model
         self.rows = int(rows)
         self.lang = model._resolve_language(language)
@@ -47,11 +49,16 @@ class ContinuousTranscriber:
         self._lang_ids = model._tokenizer.encode(f" {self.lang}")
         self.max_prompt = len(build_prompt(n_audio, self._lang_ids))
         self._q: "queue.Queue" = queue.Queue()
+        self._enc_q: "queue.Queue" = queue.Queue()           # (scheduler items, event on the encoder stream) or _STOP
+        self._encode_thread = bool(encode_thread)
         self._closed = False
         self.stats: dict = {}
         self._err: Optional[BaseException] = None
         self._th = threading.Thread(target=self._loop, name="q3asr-rows", daemon=True)
+        self._th_enc = threading.Thread(target=self._encode_loop, name="q3asr-encode", daemon=True) if self._encode_thread else None
         self._th.start()
+        if self._th_enc is not None:
+            self._th_enc.start()
 
     # ------------------------------------------------------------------ client side
     def submit(self, audio, max_tokens: Optional[int] = None) -> Future:
@@ -79,6 +86,8 @@ class ContinuousTranscriber:
         if not self._closed:
             self._closed = True
             self._q.put(_STOP)
+            if self._th_enc is not None:
+                self._th_enc.join()
             self._th.join()
         if self._err is not None:
             raise self._err
@@ -123,6 +132,59 @@ class ContinuousTranscriber:
                 o += c
         return out
 
+    def _encode_loop(self) -> None:
+        """Second thread: raw segments -> encoder features on its own lane and stream, handed over with an event."""
+        import torch
+        from .decoder import set_lane
+        dev = self.model._decoder.device
+        try:
+            set_lane(self.lane + 1)
+            with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                while True:
+                    segs, stop = self._drain(block=True)
+                    if segs:
+                        try:
+                            items = self._encode(segs)
+                        except BaseException as e:            # noqa: BLE001
+                            for seg in segs:
+                                if not seg[0]["future"].done():
+                                    seg[0]["future"].set_exception(e)
+                            raise
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream())
+                        self._enc_q.put((items, ev))
+                    if stop:
+                        break
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:                            # noqa: BLE001
+            self._err = self._err or e
+        finally:
+            self._enc_q.put(_STOP)
+
+    def _arrivals(self, block: bool, side):
+        """Scheduler items that are ready to be admitted, and whether no more will come."""
+        import torch
+        if not self._encode_thread:
+            segs, stop = self._drain(block)
+            return (self._encode(segs) if segs else []), stop
+        items, stop = [], False
+        try:
+            got = self._enc_q.get(timeout=0.05) if block else self._enc_q.get_nowait()
+            while True:
+                if got is _STOP:
+                    stop = True
+                else:
+                    batch, ev = got
+                    torch.cuda.current_stream().wait_event(ev)
+                    for it in batch:
+                        it[1].record_stream(side)             # allocated on the encoder's stream, read on the scheduler's
+                        it[1].record_stream(torch.cuda.current_stream())
+                    items += batch
+                got = self._enc_q.get_nowait()
+        except queue.Empty:
+            pass
+        return items, stop
+
     def _resolve(self, key, tokens: list) -> None:
         req, k = key
         req["texts"][k] = self.model._decode_output(tokens)
@@ -147,10 +209,9 @@ class ContinuousTranscriber:
                     idle = not sch.active() and not pending
                     if idle and stopping:
                         break
-                    segs, stop = self._drain(block=idle and not stopping)
+                    items, stop = self._arrivals(idle and not stopping, sch.side)
                     stopping = stopping or stop
-                    if segs:
-                        items = self._encode(segs)
+                    if items:
                         inflight.update({(id(it[0][0]), it[0][1]): it[0] for it in items})
                         pending.extend(items)
                     for key, toks in sch.harvest():

@@ -632,7 +632,8 @@ def test_continuous_batching_with_sampling_is_reproducible(dev, small):
     assert c != a                                        # a different seed draws differently
 
 
-def test_queue_front_door_equals_transcribe(dev, small):
+@pytest.mark.parametrize("encode_thread", [True, False])
+def test_queue_front_door_equals_transcribe(dev, small, encode_thread):
     """serve.ContinuousTranscriber: requests submitted from several threads at different times, ragged budgets, one clip long
     enough to be split into segments; every future resolves to what transcribe() returns for the same audio and options."""
     import threading
@@ -645,7 +646,8 @@ def test_queue_front_door_equals_transcribe(dev, small):
     want = [model.transcribe(x, max_tokens=m).text for x, m in zip(xs, budgets)]
     want_long = model.transcribe(long_clip, chunk_duration=2.0)            # segments decode with their own budgets (>= 256)
     futs: dict = {}
-    with ContinuousTranscriber(model, rows=4, chunk_duration=2.0, max_new_tokens=400, min_admit=1, check_every=4) as srv:
+    with ContinuousTranscriber(model, rows=4, chunk_duration=2.0, max_new_tokens=400, min_admit=1, check_every=4,
+                               encode_thread=encode_thread) as srv:
         def client(ids, delay):
             for i in ids:
                 time.sleep(delay)

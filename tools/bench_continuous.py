@@ -70,20 +70,22 @@ r3, t3 = timed("refilled rows, two lanes, best min_admit")
 s3 = [dict(s) for s in model.last_continuous_stats]
 # the queue front door: every job submitted at once from a client thread, results awaited
 from qwen3_asr_mlx_amd.serve import ContinuousTranscriber  # noqa: E402
-srv = ContinuousTranscriber(model, rows=max_batch, chunk_duration=60.0, max_new_tokens=256, min_admit=model.min_admit)
-for f in [srv.submit(j[1], max_tokens=j[2]) for j in jobs[:max_batch]]:      # warm-up: plans, graph
-    f.result()
-ts = []
-for _ in range(3):
-    torch.cuda.synchronize()
-    q0 = time.perf_counter()
-    futs = [srv.submit(j[1], max_tokens=j[2]) for j in jobs]
-    t4 = [f.result().text for f in futs]
-    ts.append(time.perf_counter() - q0)
-srv.close()
-r4 = {"mode": "queue front door (ContinuousTranscriber), all jobs submitted at once", "wall_s": round(min(ts), 4), "rtf": round(audio_s / min(ts), 1),
-      "texts_equal_fixed": t4 == t0}
-out["runs"] = [r0, r1] + sweep + [r2, r3, r4]
+fd = []
+for enc_thread in (False, True):
+    srv = ContinuousTranscriber(model, rows=max_batch, chunk_duration=60.0, max_new_tokens=256, min_admit=model.min_admit, encode_thread=enc_thread)
+    for f in [srv.submit(j[1], max_tokens=j[2]) for j in jobs[:max_batch]]:      # warm-up: plans, graph
+        f.result()
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        futs = [srv.submit(j[1], max_tokens=j[2]) for j in jobs]
+        t4 = [f.result().text for f in futs]
+        ts.append(time.perf_counter() - q0)
+    srv.close()
+    fd.append({"mode": "queue front door (ContinuousTranscriber), all jobs submitted at once, encoder " + ("on its own thread and stream" if enc_thread else "between decode chunks"),
+               "wall_s": round(min(ts), 4), "rtf": round(audio_s / min(ts), 1), "texts_equal_fixed": t4 == t0})
+out["runs"] = [r0, r1] + sweep + [r2, r3] + fd
 out["texts_equal"] = t0 == t1 == t2 == t3
 out["differing"] = {"fixed2_vs_fixed1": sum(a != b for a, b in zip(t0, t1)), "refill1_vs_fixed1": sum(a != b for a, b in zip(t0, t2)),
                     "refill2_vs_fixed1": sum(a != b for a, b in zip(t0, t3)), "first": [i for i, (a, b) in enumerate(zip(t0, t2)) if a != b][:5]}
