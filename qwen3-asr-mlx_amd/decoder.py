@@ -217,21 +217,19 @@ class TextDecoder:
         plans = self._plans.setdefault(current_lane(), {})   # per lane: eviction frees index tensors another lane could still be reading
         pl = plans.get(key)
         if pl is None:
+            import numpy as np
             import torch
             cfg, dev = self.config, self.device
-            row_b, row_pos, starts, last = [], [], [], []
-            m = 0
-            for b, t in zip(slots, seq_lens):
-                starts.append(m)
-                row_b += [b] * t
-                row_pos += list(range(t))
-                m += t
-                last.append(m - 1)
-            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
-            pl = {"row_b": i32(row_b), "row_pos": i32(row_pos), "seg_start": i32(starts), "seg_len": i32(list(seq_lens)),
-                  "last": i32(last), "M": m, "max_len": max(seq_lens),
-                  "kv_off": torch.tensor([b * cfg.num_key_value_heads * Lmax * cfg.head_dim for b in slots],
-                                         dtype=torch.int64, device=dev)}
+            lens = np.asarray(seq_lens, dtype=np.int64)
+            ends = np.cumsum(lens)
+            starts = ends - lens
+            m = int(ends[-1])
+            row_b = np.repeat(np.asarray(slots, dtype=np.int32), lens)
+            row_pos = (np.arange(m, dtype=np.int64) - np.repeat(starts, lens)).astype(np.int32)
+            i32 = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.int32)).to(dev)      # noqa: E731
+            pl = {"row_b": i32(row_b), "row_pos": i32(row_pos), "seg_start": i32(starts), "seg_len": i32(lens),
+                  "last": i32(ends - 1), "M": m, "max_len": int(lens.max()),
+                  "kv_off": torch.from_numpy(np.asarray(slots, dtype=np.int64) * (cfg.num_key_value_heads * Lmax * cfg.head_dim)).to(dev)}
             if len(plans) > 64:
                 plans.clear()
             plans[key] = pl

@@ -14,26 +14,27 @@ def _merge(enc_feats, ids_per_seq: Sequence[Sequence[int]], tok_counts: Sequence
            audio_pad_id: int = AUDIO_PAD_TOKEN_ID):
     """Packed prompt embeddings bf16 [sum T][H]: audio-pad rows <- encoder rows (in order, rounded
     to bf16), others <- embedding rows (reference generate.py:46-81)."""
+    import numpy as np
     import torch
-    ids, src = [], []
+    ids_parts, src_parts = [], []
     base = 0
     for seq, n_enc in zip(ids_per_seq, tok_counts):
-        n_pad = 0
-        for t in seq:
-            if t == audio_pad_id:
-                src.append(base + n_pad)
-                n_pad += 1
-            else:
-                src.append(-1)
+        a = np.asarray(seq, dtype=np.int32)
+        pad = a == audio_pad_id
+        n_pad = int(pad.sum())
         if n_pad and n_pad != n_enc:
             raise ValueError(f"Number of audio-pad tokens ({n_pad}) does not match encoder output length ({n_enc}).")
-        if not n_pad:                                     # no placeholders: pure text (generate.py:55-56)
-            src[len(src) - len(seq):] = [-1] * len(seq)
-        ids += list(seq)
+        srow = np.full(a.shape, -1, dtype=np.int32)          # no placeholders: pure text (generate.py:55-56)
+        if n_pad:
+            srow[pad] = base + np.arange(n_pad, dtype=np.int32)
+        ids_parts.append(a)
+        src_parts.append(srow)
         base += n_enc
+    ids = np.concatenate(ids_parts) if ids_parts else np.zeros(0, np.int32)
+    src = np.concatenate(src_parts) if src_parts else np.zeros(0, np.int32)
     dev = decoder.device
-    ids_t = torch.tensor(ids, dtype=torch.int32, device=dev)
-    src_t = torch.tensor(src, dtype=torch.int32, device=dev)
+    both = torch.from_numpy(np.stack([ids, src])).to(dev)                 # one upload
+    ids_t, src_t = both[0], both[1]
     H = decoder.config.hidden_size
     out = torch.empty((len(ids), H), dtype=torch.bfloat16, device=dev)
     enc = enc_feats if enc_feats is not None and enc_feats.numel() else None

@@ -164,9 +164,16 @@ class ContinuousTranscriber:
     def _arrivals(self, block: bool, side):
         """Scheduler items that are ready to be admitted, and whether no more will come."""
         import torch
+        # Every item carries a holder of its encoded batch: the feature tensors were allocated on another stream than the one that
+        # reads them, so they are kept alive until a synchronisation of the scheduler's stream has passed after their admission
+        # (no record_stream: its deferred event queries could land inside the decode-step capture and invalidate it).
+        def held(batch):
+            holder = {"left": len(batch), "keep": batch}
+            return [it + (holder,) for it in batch]
+
         if not self._encode_thread:
             segs, stop = self._drain(block)
-            return (self._encode(segs) if segs else []), stop
+            return (held(self._encode(segs)) if segs else []), stop
         items, stop = [], False
         try:
             got = self._enc_q.get(timeout=0.05) if block else self._enc_q.get_nowait()
@@ -176,10 +183,7 @@ class ContinuousTranscriber:
                 else:
                     batch, ev = got
                     torch.cuda.current_stream().wait_event(ev)
-                    for it in batch:
-                        it[1].record_stream(side)             # allocated on the encoder's stream, read on the scheduler's
-                        it[1].record_stream(torch.cuda.current_stream())
-                    items += batch
+                    items += held(batch)
                 got = self._enc_q.get_nowait()
         except queue.Empty:
             pass
@@ -204,29 +208,55 @@ class ContinuousTranscriber:
                 sch = RowScheduler(self.model._decoder, self.rows, self.max_prompt, self.max_new, self.sampling, self.check_every)
                 min_admit = max(1, self.rows // 8) if self.min_admit is None else max(1, int(self.min_admit))
                 pending: deque = deque()
+                retiring: list = []                          # holders whose last item was admitted since the last synchronisation
+                retired: list = []                           # ... and those one synchronisation older: dropped at the next one
                 stopping = False
+                import time as _t
+                tm = {"arrivals_s": 0.0, "harvest_s": 0.0, "admit_s": 0.0, "run_s": 0.0, "admit_calls": 0, "run_calls": 0}
+                clock = _t.perf_counter
                 while True:
                     idle = not sch.active() and not pending
                     if idle and stopping:
                         break
+                    c0 = clock()
                     items, stop = self._arrivals(idle and not stopping, sch.side)
+                    if not idle:
+                        tm["arrivals_s"] += clock() - c0
                     stopping = stopping or stop
                     if items:
                         inflight.update({(id(it[0][0]), it[0][1]): it[0] for it in items})
                         pending.extend(items)
-                    for key, toks in sch.harvest():
+                    c0 = clock()
+                    ended = sch.harvest()                    # synchronises the scheduler's stream if anything was queued since
+                    retired.clear()                          # ... so batches whose every item was admitted before it can go
+                    retired, retiring = retiring, retired
+                    for key, toks in ended:
                         self._resolve(key, toks)
                         inflight.pop((id(key[0]), key[1]), None)
+                    tm["harvest_s"] += clock() - c0          # includes waiting for the decode steps in flight
                     free = sch.free_rows()
                     # rows freed one at a time wait for company (a packed prefill of 4 costs little more than one of 1), unless
                     # nothing else is running or nothing more can arrive
-                    if pending and free and (len(free) >= min(min_admit, len(pending)) or not sch.active()):
-                        sch.admit([pending.popleft() for _ in range(min(len(free), len(pending)))])
+                    need = min_admit if len(pending) < self.rows // 2 else max(min_admit, self.rows // 4)      # a backlog can wait for a
+                    if pending and free and (len(free) >= min(need, len(pending)) or not sch.active()):        # larger, cheaper prefill
+                        c0 = clock()
+                        group = [pending.popleft() for _ in range(min(len(free), len(pending)))]
+                        sch.admit(group)
+                        for it in group:
+                            it[4]["left"] -= 1
+                            if it[4]["left"] == 0:
+                                retiring.append(it[4])
+                        del group
+                        tm["admit_s"] += clock() - c0
+                        tm["admit_calls"] += 1
                         continue
+                    c0 = clock()
                     sch.run()
+                    tm["run_s"] += clock() - c0
+                    tm["run_calls"] += 1
                 sch.finish()
                 torch.cuda.current_stream().synchronize()
-                self.stats = dict(sch.stats)
+                self.stats = dict(sch.stats, **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in tm.items()})
         except BaseException as e:                            # noqa: BLE001
             self._err = e
             for key in inflight.values():
