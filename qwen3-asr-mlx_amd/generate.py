@@ -154,6 +154,9 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
     return (out, ws, cache) if return_state else out
 
 
+_RESERVED = object()          # RowScheduler: row being prefilled on the admission stream
+
+
 class RowScheduler:
     """`rows` decode rows over one KV cache and one captured decode step; sequences are admitted into free rows (their prompts
     packed into one prefill that writes only those rows) and harvested when they end.  The building block of
@@ -177,6 +180,8 @@ class RowScheduler:
         self.captured = False
         self.stats = {"steps": 0, "admissions": 0, "checks": 0, "row_steps_used": 0, "rows": self.B}
         self.side = _side_stream(self.dev)
+        self.adm = torch.cuda.Stream(device=self.dev)          # admission prefills beside the decode steps (admit_async)
+        self._adm = None                                       # (rows, items, event, row index tensor) of the one in flight
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
             self.ws.finished.fill_(1)                # rows without a sequence stay inert
@@ -189,7 +194,69 @@ class RowScheduler:
         return [r for r in range(self.B) if self.owner[r] is None]
 
     def active(self) -> int:
-        return sum(o is not None for o in self.owner)
+        return sum(o is not None and o is not _RESERVED for o in self.owner)
+
+    def admitting(self) -> bool:
+        return self._adm is not None
+
+    def admit_async(self, items: Sequence) -> None:
+        """Like admit(), but the prefill runs on a second stream beside the decode steps of the running rows (MFMA-bound work
+        beside latency-bound work).  The target rows are parked first (position -1: the decode attention returns at once for
+        such a row, so no step in flight touches its cache while the prefill writes it); poll() activates them once the
+        prefill has finished.  One admission in flight at a time."""
+        import torch
+        if self._adm is not None:
+            raise RuntimeError("admit_async: an admission is already in flight")
+        rows = self.free_rows()[: len(items)]
+        if len(rows) < len(items):
+            raise ValueError(f"admit_async: {len(items)} sequences for {len(rows)} free rows")
+        seq_lens = [len(it[2]) for it in items]
+        counts = [int(it[1].shape[0]) for it in items]
+        budgets = [int(it[3]) for it in items]
+        if max(seq_lens) > self.max_prompt or max(budgets) > self.max_new or min(budgets) < 1:
+            raise ValueError(f"admit_async: prompt of {max(seq_lens)} tokens / budget {max(budgets)} exceeds this scheduler's {self.max_prompt} / {self.max_new}")
+        with torch.cuda.stream(self.side):
+            idx = torch.tensor(rows, dtype=torch.long, device=self.dev)
+            self.ws.pos.index_fill_(0, idx, -1)
+        self.adm.wait_stream(self.side)
+        self.adm.wait_stream(torch.cuda.current_stream())        # the features were produced on the caller's stream
+        with torch.cuda.stream(self.adm):
+            packed = torch.cat([torch.as_tensor(it[1]).to(self.dev, torch.float32).reshape(c, -1) for it, c in zip(items, counts)])
+            embeds = _merge(packed, [it[2] for it in items], counts, self.dec)
+            self.dec.prefill(embeds, seq_lens, self.cache, logits_out=self.admit_logits, slots=rows)
+            ev = torch.cuda.Event()
+            ev.record(self.adm)
+        for r in rows:
+            self.owner[r] = _RESERVED
+        self._adm = (rows, list(items), ev, idx, seq_lens, budgets)
+        self.stats["admissions"] += len(items)
+        self.stats["async_admissions"] = self.stats.get("async_admissions", 0) + 1
+        self._fresh = False
+
+    def poll(self, wait: bool = False):
+        """Activate the admission in flight if its prefill has finished (or wait for it): counters reset, first tokens drawn on
+        the decode stream.  Returns the items activated, or None."""
+        import torch
+        if self._adm is None:
+            return None
+        rows, items, ev, idx, seq_lens, budgets = self._adm
+        if not wait and not ev.query():
+            return None
+        ws = self.ws
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=self.dev)      # noqa: E731
+            ws.n_gen.index_fill_(0, idx, 0)
+            ws.finished.index_fill_(0, idx, 0)
+            ws.pos.index_copy_(0, idx, i32([t - 1 for t in seq_lens]))
+            ws.max_new.index_copy_(0, idx, i32(budgets))
+            for j, r in enumerate(rows):
+                self.dec.sample_rows(ws, self.admit_logits[j], r, self.sampling)
+        for r, it, b in zip(rows, items, budgets):
+            self.owner[r], self.budget[r] = it[0], b
+        self._adm = None
+        self._fresh = False
+        return items
 
     def admit(self, items: Sequence) -> None:
         """items: (key, feats fp32 [N][H], prompt ids, max_tokens) -- at most as many as there are free rows.  Prefill, reset
@@ -239,7 +306,7 @@ class RowScheduler:
         """[(key, token ids)] of the sequences that have ended (EOS or budget); their rows become free."""
         import torch
         self._look()
-        ended = [r for r in range(self.B) if self.owner[r] is not None and self._fin[r]]
+        ended = [r for r in range(self.B) if self.owner[r] is not None and self.owner[r] is not _RESERVED and self._fin[r]]
         if not ended:
             return []
         with torch.cuda.stream(self.side):
@@ -255,7 +322,7 @@ class RowScheduler:
         """Decode until the next look: check_every steps, or fewer if a row must end by budget before that."""
         import torch
         self._look()
-        act = [r for r in range(self.B) if self.owner[r] is not None and not self._fin[r]]
+        act = [r for r in range(self.B) if self.owner[r] is not None and self.owner[r] is not _RESERVED and not self._fin[r]]
         if not act:
             return 0
         k = max(1, min(self.check_every, min(self.budget[r] - self._ngen[r] for r in act)))
@@ -280,7 +347,8 @@ class RowScheduler:
 def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence[Sequence[int]], max_tokens: Sequence[int],
                         slots: int = 32, temperature: float = 0.0, top_p: float = 1.0, top_k: int = 0,
                         repetition_penalty: float = 1.0, repetition_context_size: int = 100, seed: int = 0,
-                        check_every: int = 16, min_admit: Optional[int] = None, stats: Optional[dict] = None) -> list[list[int]]:
+                        check_every: int = 16, min_admit: Optional[int] = None, stats: Optional[dict] = None,
+                        async_admit: bool = False) -> list[list[int]]:
     """Any number of sequences through `slots` decode rows: a row whose sequence has ended (EOS or budget) is handed to the
     next waiting sequence, whose prompt is prefilled into that row of the KV cache while the other rows keep their state
     (the reference decodes one utterance at a time, model.py:239).  `feats[i]`: encoder output
@@ -288,7 +356,9 @@ def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence
     (and the reference loop's) token for token: a row's arithmetic does not depend on its neighbours, its row index or the
     cache capacity.  With temperature > 0 the draws depend on the row a sequence lands in (reproducible, but not equal
     to a standalone call).  `min_admit`: free rows to wait for before prefilling (one packed prefill of several prompts
-    costs little more than a prefill of one; default rows / 8), ignored once nothing else is running."""
+    costs little more than a prefill of one; default rows / 8), ignored once nothing else is running.  `async_admit`: run
+    the admission prefills on a second stream beside the decode steps (RowScheduler.admit_async) -- measured neutral at
+    min_admit = rows / 8 and +30 % when rows are refilled one at a time (tools/bench_continuous.py)."""
     from collections import deque
     n = len(prompts)
     if n == 0:
@@ -309,14 +379,20 @@ def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence
     while True:
         for key, toks in sch.harvest():
             out[key] = toks
+        sch.poll(wait=not sch.active())                                    # an admission in flight: activate it when it is done
         free = sch.free_rows()
-        if waiting and free and (len(free) >= min(min_admit, len(waiting)) or not sch.active()):
+        if waiting and free and not sch.admitting() and (len(free) >= min(min_admit, len(waiting)) or not sch.active()):
             take = [waiting.popleft() for _ in range(min(len(free), len(waiting)))]
-            sch.admit([(u, feats[u], prompts[u], mt[u]) for u in take])
-            continue                                                       # a budget of 1 ends at the first token
-        if not sch.active():
+            group = [(u, feats[u], prompts[u], mt[u]) for u in take]
+            if async_admit and sch.active():
+                sch.admit_async(group)                                     # prefill beside the running rows' decode steps
+            else:
+                sch.admit(group)
+                continue                                                   # a budget of 1 ends at the first token
+        if sch.active():
+            sch.run()
+        elif not sch.admitting():
             break
-        sch.run()
     sch.finish()
     if stats is not None:
         stats.update(sch.stats)

@@ -27,7 +27,7 @@ class ContinuousTranscriber:
     def __init__(self, model: Qwen3ASR, rows: int = 32, language: Optional[str] = None, temperature: float = 0.0, top_p: float = 1.0,
                  top_k: int = 0, repetition_penalty: float = 1.2, repetition_context_size: int = 100, seed: int = 0,
                  chunk_duration: float = 30.0, max_new_tokens: int = 1750, lane: int = 7, check_every: int = 16,
-                 min_admit: Optional[int] = None, max_wait_rows: int = 64, encode_thread: bool = True) -> None:
+                 min_admit: Optional[int] = None, max_wait_rows: int = 64, encode_thread: bool = True, async_admit: bool = False) -> None:
         """`chunk_duration`: audio longer than this is split at low-energy points (as transcribe() does at 1200 s) so that every
         sequence fits the row capacity, which is sized for chunk_duration + 5 s of audio and `max_new_tokens` new tokens.
         `lane`: decoder lane of the worker thread (keep it different from lanes used elsewhere in the process).
@@ -51,6 +51,7 @@ class ContinuousTranscriber:
         self._q: "queue.Queue" = queue.Queue()
         self._enc_q: "queue.Queue" = queue.Queue()           # (scheduler items, event on the encoder stream) or _STOP
         self._encode_thread = bool(encode_thread)
+        self._async_admit = bool(async_admit)                # admission prefills on a second stream beside the decode steps
         self._closed = False
         self.stats: dict = {}
         self._err: Optional[BaseException] = None
@@ -214,8 +215,15 @@ class ContinuousTranscriber:
                 import time as _t
                 tm = {"arrivals_s": 0.0, "harvest_s": 0.0, "admit_s": 0.0, "run_s": 0.0, "admit_calls": 0, "run_calls": 0}
                 clock = _t.perf_counter
+
+                def settle(group):                           # every item of an encoded batch admitted -> the batch may go (two
+                    for it in group:                         # synchronisations of the decode stream later)
+                        it[4]["left"] -= 1
+                        if it[4]["left"] == 0:
+                            retiring.append(it[4])
+
                 while True:
-                    idle = not sch.active() and not pending
+                    idle = not sch.active() and not pending and not sch.admitting()
                     if idle and stopping:
                         break
                     c0 = clock()
@@ -234,22 +242,26 @@ class ContinuousTranscriber:
                         self._resolve(key, toks)
                         inflight.pop((id(key[0]), key[1]), None)
                     tm["harvest_s"] += clock() - c0          # includes waiting for the decode steps in flight
+                    done_group = sch.poll(wait=not sch.active())         # admission in flight: activate its rows when the prefill is done
+                    if done_group:
+                        settle(done_group)
                     free = sch.free_rows()
                     # rows freed one at a time wait for company (a packed prefill of 4 costs little more than one of 1), unless
                     # nothing else is running or nothing more can arrive
                     need = min_admit if len(pending) < self.rows // 2 else max(min_admit, self.rows // 4)      # a backlog can wait for a
-                    if pending and free and (len(free) >= min(need, len(pending)) or not sch.active()):        # larger, cheaper prefill
+                    if pending and free and not sch.admitting() and (len(free) >= min(need, len(pending)) or not sch.active()):   # larger prefill
                         c0 = clock()
                         group = [pending.popleft() for _ in range(min(len(free), len(pending)))]
-                        sch.admit(group)
-                        for it in group:
-                            it[4]["left"] -= 1
-                            if it[4]["left"] == 0:
-                                retiring.append(it[4])
+                        if self._async_admit and sch.active():
+                            sch.admit_async(group)           # prefill on a second stream beside the running rows' decode steps
+                        else:
+                            sch.admit(group)
+                            settle(group)
                         del group
                         tm["admit_s"] += clock() - c0
                         tm["admit_calls"] += 1
-                        continue
+                        if not sch.admitting():
+                            continue
                     c0 = clock()
                     sch.run()
                     tm["run_s"] += clock() - c0

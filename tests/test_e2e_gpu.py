@@ -214,8 +214,8 @@ def _encoded(model, xs, dev):
     return feats, [build_prompt(int(c), lang_ids) for c in counts]
 
 
-@pytest.mark.parametrize("slots,check_every", [(4, 16), (3, 5), (32, 16)])
-def test_continuous_batching_equals_single_sequence_runs(dev, small, slots, check_every):
+@pytest.mark.parametrize("slots,check_every,async_admit", [(4, 16, False), (3, 5, False), (32, 16, False), (4, 16, True), (3, 2, True)])
+def test_continuous_batching_equals_single_sequence_runs(dev, small, slots, check_every, async_admit):
     """13 sequences with ragged budgets through `slots` decode rows that are refilled (prefill into one
     row of a live KV cache) as sequences end: token-identical to decoding each sequence alone."""
     from qwen3_asr_mlx_amd.generate import generate_continuous
@@ -226,12 +226,14 @@ def test_continuous_batching_equals_single_sequence_runs(dev, small, slots, chec
     feats, prompts = _encoded(model, xs, dev)
     stats: dict = {}
     got = generate_continuous(model._decoder, feats, prompts, budgets, slots=slots, repetition_penalty=1.2, check_every=check_every,
-                              stats=stats)
+                              stats=stats, async_admit=async_admit, min_admit=1 if async_admit else None)
     assert got == want
     assert [len(t) for t in got] == budgets
     assert stats["admissions"] == len(budgets) and stats["rows"] == min(slots, len(budgets))
     assert stats["row_steps_used"] == sum(budgets)
-    if slots < len(budgets):                             # fewer decode steps than fixed batches of `slots` in the given order need
+    if async_admit:                                      # prefills ran on the second stream, beside the decode steps
+        assert stats.get("async_admissions", 0) >= 1
+    elif slots < len(budgets):                           # fewer decode steps than fixed batches of `slots` in the given order need
         fixed = sum(max(budgets[i: i + slots]) - 1 for i in range(0, len(budgets), slots))
         assert stats["steps"] <= fixed
 
@@ -632,8 +634,8 @@ def test_continuous_batching_with_sampling_is_reproducible(dev, small):
     assert c != a                                        # a different seed draws differently
 
 
-@pytest.mark.parametrize("encode_thread", [True, False])
-def test_queue_front_door_equals_transcribe(dev, small, encode_thread):
+@pytest.mark.parametrize("encode_thread,async_admit", [(True, False), (False, False), (True, True)])
+def test_queue_front_door_equals_transcribe(dev, small, encode_thread, async_admit):
     """serve.ContinuousTranscriber: requests submitted from several threads at different times, ragged budgets, one clip long
     enough to be split into segments; every future resolves to what transcribe() returns for the same audio and options."""
     import threading
@@ -647,7 +649,7 @@ def test_queue_front_door_equals_transcribe(dev, small, encode_thread):
     want_long = model.transcribe(long_clip, chunk_duration=2.0)            # segments decode with their own budgets (>= 256)
     futs: dict = {}
     with ContinuousTranscriber(model, rows=4, chunk_duration=2.0, max_new_tokens=400, min_admit=1, check_every=4,
-                               encode_thread=encode_thread) as srv:
+                               encode_thread=encode_thread, async_admit=async_admit) as srv:
         def client(ids, delay):
             for i in ids:
                 time.sleep(delay)
