@@ -72,6 +72,8 @@ class ContinuousTranscriber:
             fut.set_result(TranscriptionResult(text="", language="Unknown", duration=0.0))
             return fut
         jobs, _ = plan_jobs([samples], self.chunk_duration, max_tokens)
+        if any(len(j[1]) < 160 for j in jobs):               # same error transcribe() raises, before anything is queued
+            raise ValueError("audio shorter than one hop (160 samples) has no mel frames")
         if any(j[2] > self.max_new for j in jobs):
             raise ValueError(f"max_tokens {max(j[2] for j in jobs)} exceeds this transcriber's max_new_tokens={self.max_new}")
         req = {"future": fut, "texts": [None] * len(jobs), "left": len(jobs), "duration": len(samples) / 16_000,
@@ -146,11 +148,13 @@ class ContinuousTranscriber:
                     if segs:
                         try:
                             items = self._encode(segs)
-                        except BaseException as e:            # noqa: BLE001
+                        except Exception as e:                # noqa: BLE001  -- these requests fail, the service goes on
                             for seg in segs:
                                 if not seg[0]["future"].done():
                                     seg[0]["future"].set_exception(e)
-                            raise
+                            if stop:
+                                break
+                            continue
                         ev = torch.cuda.Event()
                         ev.record(torch.cuda.current_stream())
                         self._enc_q.put((items, ev))

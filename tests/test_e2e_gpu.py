@@ -666,6 +666,8 @@ def test_queue_front_door_equals_transcribe(dev, small, encode_thread, async_adm
         assert empty.result(timeout=5).text == ""
         with pytest.raises(ValueError):
             srv.submit(xs[0], max_tokens=401)
+        with pytest.raises(ValueError):
+            srv.submit(np.zeros(100, dtype=np.float32))                     # shorter than one hop, as transcribe()
     assert got == want
     assert res_long.text == want_long.text and res_long.duration == want_long.duration and res_long.language == "English"
     assert srv.stats["admissions"] >= len(xs) + 2 and srv.stats["rows"] == 4
