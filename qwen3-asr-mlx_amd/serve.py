@@ -52,6 +52,8 @@ class ContinuousTranscriber:
         self._enc_q: "queue.Queue" = queue.Queue()           # (scheduler items, event on the encoder stream) or _STOP
         self._encode_thread = bool(encode_thread)
         self._async_admit = bool(async_admit)                # admission prefills on a second stream beside the decode steps
+        self._saturated = False                              # set by the worker: encoded requests are waiting for a free row
+        self.gather_min, self.gather_s = 8, 0.1              # while saturated: collect this many segments / wait this long per encoder batch
         self._closed = False
         self.stats: dict = {}
         self._err: Optional[BaseException] = None
@@ -103,8 +105,12 @@ class ContinuousTranscriber:
 
     # ------------------------------------------------------------------ worker
     def _drain(self, block: bool):
-        """Segments that have arrived: [(req, k, samples, budget)], and whether the stop marker was seen."""
+        """Segments that have arrived: [(req, k, samples, budget)], and whether the stop marker was seen.  While the decode rows
+        are saturated (requests are waiting for a row anyway) it keeps collecting for up to `gather_s`, so that the encoder
+        runs on a batch: one clip alone costs 4.3 ms of launch-bound GPU work, eight together 0.8 ms each."""
+        import time
         items, stop = [], False
+        deadline = None
         try:
             got = self._q.get(timeout=0.05) if block else self._q.get_nowait()
             while True:
@@ -112,9 +118,18 @@ class ContinuousTranscriber:
                     stop = True
                 else:
                     items += got
-                if len(items) >= self.max_wait_rows:
+                if len(items) >= self.max_wait_rows or stop:
                     break
-                got = self._q.get_nowait()
+                try:
+                    got = self._q.get_nowait()
+                except queue.Empty:
+                    if not (self._saturated and self._encode_thread and len(items) < self.gather_min):
+                        break
+                    deadline = deadline or time.perf_counter() + self.gather_s
+                    left = deadline - time.perf_counter()
+                    if left <= 0:
+                        break
+                    got = self._q.get(timeout=left)
         except queue.Empty:
             pass
         return items, stop
@@ -246,6 +261,7 @@ class ContinuousTranscriber:
                         self._resolve(key, toks)
                         inflight.pop((id(key[0]), key[1]), None)
                     tm["harvest_s"] += clock() - c0          # includes waiting for the decode steps in flight
+                    self._saturated = len(pending) > 0 and not sch.free_rows()
                     done_group = sch.poll(wait=not sch.active())         # admission in flight: activate its rows when the prefill is done
                     if done_group:
                         settle(done_group)
