@@ -147,6 +147,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(const void* __rest
         x2 = bf2f(base[lane + 64]);
     }
     const int b = row_b[m], pos = row_pos[m];
+    // index vectors come from device memory the C-ABI cannot validate: a position outside the cache (or a negative row)
+    // drops the cache write instead of storing out of bounds (r1 fault record: a freed index vector held positions where
+    // rows were expected)
+    const bool in_cache = b >= 0 && (unsigned)pos < (unsigned)Lmax;
+    if (hs >= nh && !in_cache) return;
     if (hs >= nh + nkv) {                                   // v: plain append
         bf16* dst = v_cache + (((long)b * nkv + (hs - nh - nkv)) * Lmax + pos) * 128;
         dst[lane] = f2bf(x1);
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_rows_kernel(const bf16* _
     for (int hs = tid >> 3; hs < slots; hs += 32) {
         const bf16* src = qkv + (long)m * ld + hs * 128 + 8 * sub;
         const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(src), v2 = *reinterpret_cast<const bf16x8*>(src + 64);
+        if (hs >= nh && !(b >= 0 && (unsigned)pos < (unsigned)Lmax)) continue;   // outside the cache: no store (see above)
         if (hs >= nh + nkv) {                               // v: plain append
             bf16* dst = v_cache + (((long)b * nkv + (hs - nh - nkv)) * Lmax + pos) * 128 + 8 * sub;
             *reinterpret_cast<bf16x8*>(dst) = v1;

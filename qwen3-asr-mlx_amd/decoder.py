@@ -464,7 +464,11 @@ class TextDecoder:
     def capture_step(self, ws: DecodeWorkspace, cache: KVCache, sampling: dict) -> None:
         import torch
         # the graph bakes raw pointers: key it on the addresses it captured, not on Python object identity
-        key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.max_len, tuple(sorted(sampling.items())))
+        # (every buffer the captured launches address: K/V blocks AND the attention workspace -- a re-created cache can get
+        # its large K/V blocks back from the caching allocator while the small workspace lands elsewhere -- and every switch
+        # that changes which launches are recorded)
+        key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.attn_ws.data_ptr(), cache.max_len, self.decode_impl,
+               bool(self.fuse_norm), bool(self.fuse_norm_gu), tuple(sorted(sampling.items())))
         if ws.graph is not None and ws.graph_key == key:
             ws.graph_uses += 1
             if ws.graph_multi is None and ws.graph_uses >= 2:        # a workspace that keeps coming back earns the long graph

@@ -4,12 +4,15 @@ One process per GPU, full model replica each (4.08 GB of 288 GB).  Utterances sh
 only communication is the batch split and the result gather: rank 0 scatters padded float32 audio
 (1.92 MB per 30 s clip) and gathers int32 token ids -- `torch.distributed` scatter/gather, i.e. RCCL
 over xGMI with backend "nccl", gloo on CPU in tests.  No all-reduce exists anywhere on the path.
+The scattered audio stays on `device`: the per-rank run function receives the padded device tensor.
 """
 from __future__ import annotations
 
 from typing import Callable, Optional, Sequence
 
 import numpy as np
+
+_ERR_CHARS = 240          # bytes of a failing rank's message carried through the status gather
 
 
 def assign(lengths: Sequence[int], world: int) -> list[list[int]]:
@@ -19,18 +22,23 @@ def assign(lengths: Sequence[int], world: int) -> list[list[int]]:
     return [order[r::world] for r in range(world)]
 
 
-def run_sharded(run_fn: Callable[[list, list], list], audios: Optional[Sequence[np.ndarray]],
-                max_tokens: Optional[Sequence[int]], device="cpu", group=None) -> Optional[list]:
-    """Rank 0 passes the whole request (`audios`, `max_tokens`); other ranks pass None.  Every rank
-    calls `run_fn(its_audios, its_max_tokens) -> list[list[int]]`.  Rank 0 returns the token lists in
-    request order, the others None.  Result is identical to `run_fn(audios, max_tokens)` on one rank
-    whenever run_fn is batch-invariant (the HIP path is)."""
+def run_sharded(run_fn: Callable, audios, max_tokens: Optional[Sequence[int]], device="cpu", group=None) -> Optional[list]:
+    """Rank 0 passes the whole request, other ranks pass None for `audios` and `max_tokens`.  `audios` is either a sequence
+    of 1-D float32 arrays (host) or a pair ``(padded fp32 tensor [n][l] on `device`, lengths)`` already resident there.
+    Every rank calls ``run_fn(audio [m][l_max] fp32 on `device` (zero padded), lens list[int], max_tokens list[int])
+    -> list[list[int]]`` on its share (no host bounce of the audio).  Rank 0 returns the token lists in request order, the
+    others None.  The result is identical to one rank running the whole request whenever run_fn is batch-invariant (the HIP
+    path is).  An exception inside run_fn on any rank is carried through the gather: every rank completes the
+    collectives, rank 0 raises RuntimeError naming the failing ranks, the failing ranks re-raise their own exception."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     hdr = torch.zeros(3, dtype=torch.int64, device=device)
     if rank == 0:
-        lens = [len(a) for a in audios]
+        resident = isinstance(audios, tuple) and len(audios) == 2 and hasattr(audios[0], "shape") and not isinstance(audios[0], np.ndarray)
+        lens = [int(n) for n in audios[1]] if resident else [len(a) for a in audios]
+        if len(max_tokens) != len(lens):
+            raise ValueError("run_sharded: one max_tokens entry per utterance")
         parts = assign(lens, world)
         n_max = max(len(p) for p in parts)
         l_max = max(lens) if lens else 0
@@ -44,12 +52,20 @@ def run_sharded(run_fn: Callable[[list, list], list], audios: Optional[Sequence[
     if rank == 0:
         a_list, m_list = [], []
         for p in parts:
-            a = torch.zeros((n_max, l_max), dtype=torch.float32)
             m = torch.full((n_max, 2), -1, dtype=torch.int64)
             for j, i in enumerate(p):
-                a[j, : lens[i]] = torch.from_numpy(np.ascontiguousarray(audios[i], dtype=np.float32))
                 m[j, 0], m[j, 1] = lens[i], int(max_tokens[i])
-            a_list.append(a.to(device))
+            if resident:                                    # rows picked on the device: the request never visits the host
+                src = audios[0]
+                a = torch.zeros((n_max, l_max), dtype=torch.float32, device=device)
+                if p:
+                    a[: len(p), : min(l_max, src.shape[1])] = src.to(device)[torch.tensor(p, dtype=torch.long, device=device), :l_max]
+            else:
+                a = torch.zeros((n_max, l_max), dtype=torch.float32)
+                for j, i in enumerate(p):
+                    a[j, : lens[i]] = torch.from_numpy(np.ascontiguousarray(audios[i], dtype=np.float32))
+                a = a.to(device)
+            a_list.append(a)
             m_list.append(m.to(device))
         dist.scatter(my_audio, a_list, src=0, group=group)
         dist.scatter(my_meta, m_list, src=0, group=group)
@@ -57,19 +73,40 @@ def run_sharded(run_fn: Callable[[list, list], list], audios: Optional[Sequence[
         dist.scatter(my_audio, None, src=0, group=group)
         dist.scatter(my_meta, None, src=0, group=group)
     meta = my_meta.cpu()
-    mine = [j for j in range(n_max) if int(meta[j, 0]) >= 0]
-    host = my_audio.cpu().numpy()
-    toks = run_fn([host[j, : int(meta[j, 0])] for j in mine], [int(meta[j, 1]) for j in mine]) if mine else []
+    mine = [j for j in range(n_max) if int(meta[j, 0]) >= 0]                         # a prefix: rows are dealt in order
+    status = torch.zeros((1 + _ERR_CHARS,), dtype=torch.int32)
+    toks, failure = [], None
+    if mine:
+        try:
+            toks = run_fn(my_audio[: len(mine)], [int(meta[j, 0]) for j in mine], [int(meta[j, 1]) for j in mine])
+            if len(toks) != len(mine):
+                raise RuntimeError(f"run_fn returned {len(toks)} results for {len(mine)} utterances")
+        except Exception as e:                                # noqa: BLE001 -- must reach the collectives below
+            failure, toks = e, []
+            msg = f"{type(e).__name__}: {e}".encode("utf-8", "replace")[:_ERR_CHARS]
+            status[0] = 1
+            status[1: 1 + len(msg)] = torch.tensor(list(msg), dtype=torch.int32)
     out = torch.full((n_max, t_max + 1), -1, dtype=torch.int32)
     for j, t in zip(mine, toks):
         out[j, 0] = len(t)
         out[j, 1: 1 + len(t)] = torch.tensor(t, dtype=torch.int32)
-    out = out.to(device)
+    out, status = out.to(device), status.to(device)
     gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
+    stat_all = [torch.empty_like(status) for _ in range(world)] if rank == 0 else None
     dist.gather(out, gathered, dst=0, group=group)
+    dist.gather(status, stat_all, dst=0, group=group)
     if rank != 0:
+        if failure is not None:
+            raise failure
         return None
-    result: list = [None] * len(audios)
+    bad = []
+    for r in range(world):
+        s = stat_all[r].cpu()
+        if int(s[0]):
+            bad.append(f"rank {r}: " + bytes(int(c) for c in s[1:].tolist() if c).decode("utf-8", "replace"))
+    if bad:
+        raise RuntimeError("run_sharded: " + "; ".join(bad)) from failure
+    result: list = [None] * len(lens)
     for r, p in enumerate(parts):
         g = gathered[r].cpu()
         for j, i in enumerate(p):
@@ -82,7 +119,8 @@ def transcribe_sharded(model, audios: Optional[Sequence], language: Optional[str
                        chunk_duration: float = 1200.0, device="cpu", group=None, **sampling) -> Optional[list]:
     """`Qwen3ASR.transcribe_batch` over all ranks of `group`: rank 0 passes the request (others `audios=None`), plans the
     decode jobs -- one per utterance, one per low-energy-split segment of long-form audio (reference model.py:382-447) --
-    and the jobs, not the utterances, are dealt to the ranks, so a single long recording spreads over every GPU.
+    and the jobs, not the utterances, are dealt to the ranks, so a single long recording spreads over every GPU.  A rank's
+    share may hold any number of jobs (`generate_tokens_packed` walks it in batches of MAX_BATCH).
     Returns the `TranscriptionResult`s on rank 0 (None elsewhere); equal to the single-process result."""
     import torch.distributed as dist
     from .model import TranscriptionResult, plan_jobs
@@ -92,8 +130,9 @@ def transcribe_sharded(model, audios: Optional[Sequence], language: Optional[str
     if rank == 0:
         samples = [model._as_samples(a) for a in audios]
         jobs, seg_of = plan_jobs(samples, chunk_duration, max_tokens)
-    toks = run_sharded(lambda a, m: model.generate_tokens(a, m, lang, **sampling), [j[1] for j in jobs] if rank == 0 else None,
-                       [j[2] for j in jobs] if rank == 0 else None, device=device, group=group)
+    toks = run_sharded(lambda a, n, m: model.generate_tokens_packed(a, n, m, lang, **sampling),
+                       [j[1] for j in jobs] if rank == 0 else None, [j[2] for j in jobs] if rank == 0 else None,
+                       device=device, group=group)
     if rank != 0:
         return None
     texts = [model._decode_output(t) for t in toks]

@@ -345,6 +345,22 @@ class Qwen3ASR:
         return self.generate_tokens_device(audio, lens_dev, lens, max_tokens, lang, temperature, top_p, top_k,
                                            repetition_penalty, repetition_context_size, seed)
 
+    def generate_tokens_packed(self, audio, lens: Sequence[int], max_tokens: Sequence[int], lang: str, temperature=0.0,
+                               top_p=1.0, top_k=0, repetition_penalty=1.2, repetition_context_size=100, seed=None) -> list[list[int]]:
+        """Any number of utterances as ONE padded fp32 tensor [n][Lmax] already on the device (what `dist.run_sharded`
+        hands each rank): walked in batches of MAX_BATCH rows, no host copy of the audio."""
+        import torch
+        dev = self._decoder.device if self._decoder is not None else None
+        out: list[list[int]] = []
+        for s0 in range(0, len(lens), self.MAX_BATCH):
+            part = [int(n) for n in lens[s0: s0 + self.MAX_BATCH]]
+            rows = audio[s0: s0 + len(part)]
+            lens_dev = torch.tensor(part, dtype=torch.int32).to(dev, non_blocking=True)
+            sd = None if seed is None else int(seed) + s0
+            out += self.generate_tokens_device(rows, lens_dev, part, list(max_tokens[s0: s0 + len(part)]), lang, temperature, top_p,
+                                               top_k, repetition_penalty, repetition_context_size, sd)
+        return out
+
     def generate_tokens_device(self, audio, lens_dev, lens: Sequence[int], max_tokens: Sequence[int], lang: str,
                                temperature=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2,
                                repetition_context_size=100, seed=None) -> list[list[int]]:

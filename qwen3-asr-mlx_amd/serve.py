@@ -57,6 +57,7 @@ class ContinuousTranscriber:
         self._closed = False
         self.stats: dict = {}
         self._err: Optional[BaseException] = None
+        self._pending: deque = deque()                       # encoded items waiting for a row (owned by the row worker)
         self._th = threading.Thread(target=self._loop, name="q3asr-rows", daemon=True)
         self._th_enc = threading.Thread(target=self._encode_loop, name="q3asr-encode", daemon=True) if self._encode_thread else None
         self._th.start()
@@ -68,6 +69,7 @@ class ContinuousTranscriber:
         """Queue one utterance (path or 1-D float array, as transcribe()).  The future resolves to a TranscriptionResult."""
         if self._closed:
             raise RuntimeError("ContinuousTranscriber is closed")
+        self._raise_if_dead()
         fut: Future = Future()
         samples = self.model._as_samples(audio)
         if len(samples) == 0:
@@ -81,7 +83,37 @@ class ContinuousTranscriber:
         req = {"future": fut, "texts": [None] * len(jobs), "left": len(jobs), "duration": len(samples) / 16_000,
                "joined": len(samples) / 16_000 > self.chunk_duration}
         self._q.put([(req, k, j[1], int(j[2])) for k, j in enumerate(jobs)])
+        if self._err is not None:                            # the service died while this was being queued: nobody reads _q any more
+            self._fail_queued(self._err)
         return fut
+
+    def _raise_if_dead(self) -> None:
+        """A worker that has failed (or a thread that is gone) can never complete a request: refuse new ones at once."""
+        if self._err is not None:
+            raise RuntimeError(f"ContinuousTranscriber has failed: {type(self._err).__name__}: {self._err}") from self._err
+        if not self._th.is_alive() or (self._th_enc is not None and not self._th_enc.is_alive()):
+            raise RuntimeError("ContinuousTranscriber worker is not running")
+
+    def _fail_queued(self, e: BaseException) -> None:
+        """Fail every request still waiting in the raw queue or the encoded queue (called once the service is dead)."""
+        while True:
+            try:
+                got = self._q.get_nowait()
+            except queue.Empty:
+                break
+            if got is not _STOP:
+                for seg in got:
+                    if not seg[0]["future"].done():
+                        seg[0]["future"].set_exception(e)
+        while True:
+            try:
+                got = self._enc_q.get_nowait()
+            except queue.Empty:
+                break
+            if got is not _STOP:
+                for it in got[0]:
+                    if not it[0][0]["future"].done():
+                        it[0][0]["future"].set_exception(e)
 
     def transcribe(self, audio, max_tokens: Optional[int] = None) -> TranscriptionResult:
         return self.submit(audio, max_tokens).result()
@@ -160,6 +192,12 @@ class ContinuousTranscriber:
             with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
                 while True:
                     segs, stop = self._drain(block=True)
+                    if self._err is not None:                 # the row worker has failed: nothing encoded here would ever be decoded
+                        for seg in segs:
+                            if not seg[0]["future"].done():
+                                seg[0]["future"].set_exception(self._err)
+                        self._fail_queued(self._err)
+                        break
                     if segs:
                         try:
                             items = self._encode(segs)
@@ -178,6 +216,7 @@ class ContinuousTranscriber:
                 torch.cuda.current_stream().synchronize()
         except BaseException as e:                            # noqa: BLE001
             self._err = self._err or e
+            self._fail_queued(self._err)
         finally:
             self._enc_q.put(_STOP)
 
@@ -227,7 +266,7 @@ class ContinuousTranscriber:
             with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
                 sch = RowScheduler(self.model._decoder, self.rows, self.max_prompt, self.max_new, self.sampling, self.check_every)
                 min_admit = max(1, self.rows // 8) if self.min_admit is None else max(1, int(self.min_admit))
-                pending: deque = deque()
+                pending: deque = self._pending
                 retiring: list = []                          # holders whose last item was admitted since the last synchronisation
                 retired: list = []                           # ... and those one synchronisation older: dropped at the next one
                 stopping = False
@@ -290,16 +329,15 @@ class ContinuousTranscriber:
                 torch.cuda.current_stream().synchronize()
                 self.stats = dict(sch.stats, **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in tm.items()})
         except BaseException as e:                            # noqa: BLE001
-            self._err = e
+            self._err = e                                     # from here on submit() refuses and the encode loop stops
             for key in inflight.values():
                 if not key[0]["future"].done():
                     key[0]["future"].set_exception(e)
-            while True:                                       # fail what is still queued
-                try:
-                    got = self._q.get_nowait()
-                except queue.Empty:
-                    break
-                if got is not _STOP:
-                    for seg in got:
-                        if not seg[0]["future"].done():
-                            seg[0]["future"].set_exception(e)
+            for it in list(self._pending):                    # encoded, waiting for a row
+                if not it[0][0]["future"].done():
+                    it[0][0]["future"].set_exception(e)
+            self._pending.clear()
+            self._fail_queued(e)                              # raw queue and encoded queue
+        else:
+            if self._err is not None:                         # the encode thread died and sent its stop marker: same duty
+                self._fail_queued(self._err)

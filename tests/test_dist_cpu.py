@@ -16,9 +16,16 @@ def _fake_run(audios, budgets):
     """Deterministic stand-in for the per-GPU hot path: ids derived from the samples only."""
     out = []
     for a, m in zip(audios, budgets):
+        a = np.asarray(a)
         h = int(np.abs(a).sum() * 1e4) % 1000
         out.append([(h + 7 * i) % 151936 for i in range(min(m, 3 + len(a) % 5))])
     return out
+
+
+def _fake_run_packed(audio, lens, budgets):
+    """The run function `run_sharded` calls: padded tensor [m][l_max] on the group's device + lengths."""
+    assert isinstance(audio, torch.Tensor) and audio.shape[0] == len(lens) == len(budgets)
+    return _fake_run([audio[j, :n].numpy() for j, n in enumerate(lens)], budgets)
 
 
 def _request():
@@ -34,7 +41,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from qwen3_asr_mlx_amd import dist as qd
     audios, budgets = _request()
-    res = qd.run_sharded(_fake_run, audios if rank == 0 else None, budgets if rank == 0 else None)
+    res = qd.run_sharded(_fake_run_packed, audios if rank == 0 else None, budgets if rank == 0 else None)
     if rank == 0:
         q.put(res)
     dist.barrier()
@@ -77,8 +84,15 @@ class _StandInModel:
     def _as_samples(a):
         return np.asarray(a, dtype=np.float32)
 
-    def generate_tokens(self, audios, budgets, lang, **kw):
-        return _fake_run(audios, budgets)
+    MAX_BATCH = 64
+
+    def generate_tokens_packed(self, audio, lens, budgets, lang, **kw):
+        out = []
+        for s0 in range(0, len(lens), self.MAX_BATCH):                 # as Qwen3ASR.generate_tokens_packed: batches of MAX_BATCH
+            part = lens[s0: s0 + self.MAX_BATCH]
+            assert len(part) <= self.MAX_BATCH
+            out += _fake_run_packed(audio[s0: s0 + len(part)], part, budgets[s0: s0 + len(part)])
+        return out
 
     def _decode_output(self, toks):
         return "-".join(str(t) for t in toks)
@@ -130,3 +144,72 @@ def test_longform_segments_are_dealt_across_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == want
+
+
+def _worker_many(rank, world, port, q, mode):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qwen3_asr_mlx_amd import dist as qd
+    rng = np.random.default_rng(11)
+    n = 150                                                            # 75 jobs per rank: more than MAX_BATCH
+    audios = [rng.standard_normal(200 + 3 * i).astype(np.float32) for i in range(n)]
+    budgets = [3 + i % 5 for i in range(n)]
+    try:
+        if mode == "resident":                                         # request already packed on the group's device
+            lens = [len(a) for a in audios]
+            packed = torch.zeros((n, max(lens)))
+            for i, a in enumerate(audios):
+                packed[i, : lens[i]] = torch.from_numpy(a)
+            res = qd.run_sharded(_fake_run_packed, (packed, lens) if rank == 0 else None, budgets if rank == 0 else None)
+            if rank == 0:
+                q.put(("ok", res == _fake_run(audios, budgets)))
+        elif mode == "many":
+            res = qd.transcribe_sharded(_StandInModel(), audios if rank == 0 else None, max_tokens=4)
+            if rank == 0:
+                m = _StandInModel()
+                q.put(("ok", [r.text for r in res] == [m._decode_output(t) for t in _fake_run(audios, [4] * n)]))
+        else:                                                          # one rank's run function raises: nobody may hang
+            def run(audio, lens, b):
+                if rank == 1:
+                    raise ValueError("clip shorter than one hop")
+                return _fake_run_packed(audio, lens, b)
+            try:
+                qd.run_sharded(run, audios if rank == 0 else None, budgets if rank == 0 else None)
+                q.put((rank, "no error"))
+            except Exception as e:                                     # noqa: BLE001
+                q.put((rank, f"{type(e).__name__}: {e}"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn(target, world, port, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    return q, procs
+
+
+@pytest.mark.parametrize("mode", ["many", "resident"])
+def test_more_jobs_per_rank_than_max_batch(mode):
+    """a rank's share above MAX_BATCH used to raise inside generate_batch on that rank while the others
+    waited in the gather."""
+    q, procs = _spawn(_worker_many, 2, 29400 + (os.getpid() % 90) + (0 if mode == "many" else 100), mode)
+    assert q.get(timeout=180) == ("ok", True)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+
+def test_failing_rank_does_not_deadlock_the_group():
+    q, procs = _spawn(_worker_many, 2, 29800 + (os.getpid() % 90), "fail")
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] == "ValueError: clip shorter than one hop"
+    assert got[0].startswith("RuntimeError: run_sharded: rank 1: ValueError: clip shorter than one hop")
