@@ -8,11 +8,14 @@ on-device greedy sampling (repetition penalty 1.2, the API default) -> token ids
 Weights are synthetic (seeded N(0, 0.02^2), bf16, reference checkpoint layout); random weights never
 emit EOS, so every sequence decodes exactly N_dec tokens.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts the N ranks itself)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
-N > 1: rank 0 owns the request (32*N clips resident on its GPU), scatters audio and gathers token ids
-with torch.distributed (RCCL over xGMI); weights are replicated; weak scaling.
+N > 1: rank 0 owns the request (32*N clips resident on its GPU); the step is the product's own
+`dist.run_sharded` (scatter of the audio rows, per-rank hot path on the device tensor, gather of token
+ids over torch.distributed = RCCL over xGMI); weights are replicated; weak scaling.
+`value` has the batch resident in HBM when the timed region starts and includes detokenisation; the
+PCIe-inclusive rate through the public `transcribe_batch` (host arrays in, text out) is `end_to_end`.
 """
 from __future__ import annotations
 
@@ -32,6 +35,22 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 _T0 = time.perf_counter()
+
+
+def lib_sha16() -> str:
+    import hashlib
+    from qwen3_asr_mlx_amd import _lib
+    return hashlib.sha256(_lib.LIB_PATH.read_bytes()).hexdigest()[:16]
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def log(msg: str) -> None:
@@ -55,13 +74,13 @@ def decode_bytes_per_launch(cfg, B: int, bytes_per_weight: int = 2):
     return per_layer * t.num_hidden_layers + [w * t.vocab_size * H]
 
 
-def cpu_baseline(cfg, state, clip, n_dec_sample: int, n_dec_full: int):
+def cpu_baseline(cfg, state, clip, n_dec_sample: int, n_dec_full: int, threads: int = 0):
     """The oracle (CPU restatement of the reference algorithm, oracle/) timed on this host's cores on
-    ONE clip with a short decode, extrapolated to n_dec_full tokens."""
+    ONE clip with a short decode, extrapolated to n_dec_full tokens.  threads = 0: all cores of this box's share."""
     import torch
     import oracle
     # threads actually used: the affinity mask, capped at the 16-core share a one-GPU box gets
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = threads or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     log(f"cpu_baseline: {cores} threads")
     Wd = {k[len("model."):]: v.float().cpu() for k, v in state.items() if k.startswith("model.")}
@@ -93,7 +112,7 @@ def cpu_baseline(cfg, state, clip, n_dec_sample: int, n_dec_full: int):
     total = t_mel + t_enc + t_pre + (n_dec_full - 1) * t_tok
     secs = len(clip) / 16000.0
     return {
-        "value": secs / total, "unit": "audio-s/wall-s", "cores": cores, "kind": "port",
+        "value": secs / total, "unit": "audio-s/wall-s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
         "sample": (f"oracle/ (numpy mel + torch-CPU fp32 encoder/decoder, batch 1) on 1 clip of {secs:g} s: mel {t_mel:.2f} s, "
                    f"encoder {t_enc:.2f} s, prefill {t_pre:.2f} s, {n_dec_sample} decode steps at {t_tok:.3f} s/token "
                    f"extrapolated to {n_dec_full} tokens"),
@@ -114,7 +133,21 @@ def main() -> None:
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight in the throughput leg (host threads / lanes)")
     ap.add_argument("--weights", choices=("bf16", "fp8"), default="bf16",
                     help="fp8: decoder weights quantised on load (BASELINE.json configs[4]; not the headline config)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the ndec=1500 and 5 s secondary legs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start N fresh rank processes (one per GPU) BEFORE this process touches the
+        # GPU -- children of a process that never initialised HIP, never a re-exec -- and pass their output through.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        log("self-launch: " + " ".join(cmd))
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -152,38 +185,30 @@ def main() -> None:
     budgets = [args.ndec] * B
 
     # ---- request: resident in HBM before the timed region
+    detok = model._decode_output
     if world == 1:
-        audio, lens_dev, lens = q.audio.pack_audio([synth_clip(i, n) for i in range(B)], dev)
+        host_clips = [synth_clip(i, n) for i in range(B)]
+        audio, lens_dev, lens = q.audio.pack_audio(host_clips, dev)
         torch.cuda.synchronize()
 
         def step():
-            return model.generate_tokens_device(audio, lens_dev, lens, budgets, "English", repetition_penalty=1.2)
+            toks_ = model.generate_tokens_device(audio, lens_dev, lens, budgets, "English", repetition_penalty=1.2)
+            return toks_, [detok(t_) for t_ in toks_]
     else:
-        lens = [n] * B
-        lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
-        mine = torch.empty((B, n), dtype=torch.float32, device=dev)
-        parts = None
+        from qwen3_asr_mlx_amd import dist as qd
+        cdev = "cpu" if rehearse else dev                      # rehearsal: gloo moves host tensors
+        request = all_budgets = None
         if rank == 0:
-            parts = [q.audio.pack_audio([synth_clip(r * B + i, n) for i in range(B)], dev)[0] for r in range(world)]
-        tok_buf = torch.empty((B, args.ndec), dtype=torch.int32, device=dev)
-        gathered = [torch.empty_like(tok_buf) for _ in range(world)] if rank == 0 else None
+            packed = q.audio.pack_audio([synth_clip(i, n) for i in range(world * B)], dev)[0]
+            request, all_budgets = (packed.to(cdev), [n] * (world * B)), [args.ndec] * (world * B)
+        torch.cuda.synchronize()
+
+        def run_rank(a_, lens_, budgets_):                     # this rank's share: padded tensor [B][n] on `cdev`
+            return model.generate_tokens_packed(a_.to(dev), lens_, budgets_, "English", repetition_penalty=1.2)
 
         def step():
-            if rehearse:
-                host = torch.empty((B, n), dtype=torch.float32)
-                dist.scatter(host, [p_.cpu() for p_ in parts] if rank == 0 else None, src=0)
-                mine.copy_(host)
-            else:
-                dist.scatter(mine, parts, src=0)                              # RCCL over xGMI: 1.92 MB per clip
-            toks = model.generate_tokens_device(mine, lens_dev, lens, budgets, "English", repetition_penalty=1.2)
-            tok_buf.copy_(torch.tensor(toks, dtype=torch.int32))
-            if rehearse:
-                hb = tok_buf.cpu()
-                hg = [torch.empty_like(hb) for _ in range(world)] if rank == 0 else None
-                dist.gather(hb, hg, dst=0)
-            else:
-                dist.gather(tok_buf, gathered, dst=0)
-            return toks
+            toks_ = qd.run_sharded(run_rank, request, all_budgets, device=cdev)      # the product's DP path
+            return toks_, ([detok(t_) for t_ in toks_] if rank == 0 else None)
 
     for i in range(args.warmup):
         w0 = time.perf_counter()
@@ -208,13 +233,14 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         s0 = time.perf_counter()
-        toks = step()
+        toks, texts = step()
         torch.cuda.synchronize()
         per_step.append(time.perf_counter() - s0)
         log(f"timed step: {per_step[-1]:.3f}s")
     fence()
     elapsed = all_max(time.perf_counter() - t0)
-    assert all(len(t) == args.ndec for t in toks)
+    if rank == 0:
+        assert len(toks) == world * B and all(len(t) == args.ndec for t in toks) and len(texts) == len(toks)
 
     if rank != 0:
         dist.destroy_process_group()
@@ -227,7 +253,8 @@ def main() -> None:
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.weights == "bf16" else "bf16 activations, fp8-e4m3 decoder weights", "data": "synthetic",
         "config": {"workload": f"Qwen3-ASR-1.7B bf16, batch={B}/GPU, {args.clip_seconds:g} s clips, greedy (repetition_penalty 1.2), "
-                               f"{args.ndec} decoded tokens/clip, hipGraph decode" + ("" if world == 1 else f", {world}-GPU DP over RCCL"),
+                               f"{args.ndec} decoded tokens/clip, hipGraph decode, detokenised" +
+                               ("" if world == 1 else f", {world}-GPU DP (dist.run_sharded: scatter/gather over RCCL)"),
                    "batch_per_gpu": B, "clip_seconds": args.clip_seconds, "decoded_tokens": args.ndec,
                    "weights": "synthetic seeded N(0,0.02^2) bf16", "graph": not args.no_graph},
         "p50_latency_ms": 1e3 * float(np.median(per_step)),
@@ -245,6 +272,44 @@ def main() -> None:
                 np_lat.append(time.perf_counter() - s0)
         line["no_repetition_penalty"] = {"value": B * args.clip_seconds / float(np.median(np_lat)), "unit": "audio-s/wall-s",
                                          "p50_latency_ms": 1e3 * float(np.median(np_lat))}
+    if world == 1:
+        # ---- SURVEY.md 8d's end-to-end definition through the public API: host float32 arrays in (pinned staging + H2D over
+        # PCIe inside the timed region), mel -> encoder -> prefill -> decode, texts out.  Never `value` (that is HBM-resident).
+        e2e = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            res_ = model.transcribe_batch(host_clips, max_tokens=args.ndec)
+            torch.cuda.synchronize()
+            if i:
+                e2e.append(time.perf_counter() - s0)
+        assert len(res_) == B and all(isinstance(r_.text, str) for r_ in res_)
+        line["end_to_end"] = {"value": B * args.clip_seconds / float(np.median(e2e)), "unit": "audio-s/wall-s",
+                              "p50_latency_ms": 1e3 * float(np.median(e2e)),
+                              "note": "Qwen3ASR.transcribe_batch(list of host float32 arrays): H2D of the batch and detokenisation inside the timed region"}
+        log(f"end-to-end (H2D + detokenise): {line['end_to_end']['p50_latency_ms']:.1f} ms vs {line['p50_latency_ms']:.1f} ms resident")
+    if world == 1 and not args.no_extra_configs and args.weights == "bf16":
+        # ---- secondary legs SURVEY.md 8d names: the reference's own token budget max(256, 50/s) = 1500 per 30 s clip,
+        # and the 5 s configuration (32 tokens per clip)
+        def leg(clips_n, ndec_, reps):
+            a_, ld_, l_ = q.audio.pack_audio([synth_clip(i, clips_n) for i in range(B)], dev)
+            lat_ = []
+            for i in range(reps + 1):
+                torch.cuda.synchronize()
+                s0 = time.perf_counter()
+                t_ = model.generate_tokens_device(a_, ld_, l_, [ndec_] * B, "English", repetition_penalty=1.2)
+                _ = [detok(x_) for x_ in t_]
+                torch.cuda.synchronize()
+                if i:
+                    lat_.append(time.perf_counter() - s0)
+            assert all(len(x_) == ndec_ for x_ in t_)
+            m_ = float(np.median(lat_))
+            return {"value": B * clips_n / 16000.0 / m_, "unit": "audio-s/wall-s", "p50_latency_ms": 1e3 * m_,
+                    "workload": f"batch={B}, {clips_n / 16000:g} s clips, {ndec_} decoded tokens/clip"}
+        line["ndec1500"] = leg(n, 1500, 2)
+        log(f"ndec=1500: RTF {line['ndec1500']['value']:.0f}x, {line['ndec1500']['p50_latency_ms']:.0f} ms per batch")
+        line["clip5s"] = leg(80000, 32, 5)
+        log(f"5 s clips, 32 tokens: RTF {line['clip5s']['value']:.0f}x, {line['clip5s']['p50_latency_ms']:.1f} ms per batch")
     if world == 1 and B > 1:
         # ---- BASELINE.json configs[1]: batch 1, one 30 s clip, same decode budget -> latency
         a1, l1d, l1 = q.audio.pack_audio([synth_clip(0, n)], dev)
@@ -390,12 +455,17 @@ def main() -> None:
         avg_ms = ms.value / launches
         achieved = total_bytes / (ms.value * 1e-3) / 1e9
         log(f"roofline leg: {launches} skinny3 launches in {ms.value:.2f} ms")
-        traffic = None
-        pmc = ROOT / "profiles" / "r01_pmc_summary.json"
-        if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get("skinny3_hbm_bytes_per_launch")
+        # PMC traffic: only a figure collected on THIS build of the library (tools/pmc_probe.py stamps the summary with the
+        # sha-256 of libq3asr_hip.so); a summary from any other build is refused and `traffic` is null.
+        traffic, traffic_from = None, "no PMC summary for this build of libq3asr_hip.so"
+        lib_sha = lib_sha16()
+        for pmc in sorted((ROOT / "profiles").glob("r*_pmc_summary.json"), reverse=True):
+            d_ = json.loads(pmc.read_text())
+            if d_.get("lib_sha16") == lib_sha and d_.get("skinny3_hbm_bytes_per_launch"):
+                traffic, traffic_from = d_["skinny3_hbm_bytes_per_launch"], f"profiles/{pmc.name} (lib sha16 {lib_sha})"
+                break
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
                             "kernel": "skinny3_kernel (decode weight streaming, all shapes of one step)",
                             "launches_measured": launches, "avg_launch_us": 1e3 * avg_ms,
                             "bytes_per_launch": sum(per_launch) / len(per_launch)}
@@ -403,6 +473,9 @@ def main() -> None:
             model.close()
             torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline(cfg, state, synth_clip(0, n), 8, args.ndec)
+            # BASELINE.json configs[0] (5 s clip, 32 tokens) on all cores and on one (k = all and k = 1)
+            line["cpu_baseline"]["clip5s_all_cores"] = cpu_baseline(cfg, state, synth_clip(0, 80000), 4, 32)
+            line["cpu_baseline"]["clip5s_k1"] = cpu_baseline(cfg, state, synth_clip(0, 80000), 2, 32, threads=1)
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

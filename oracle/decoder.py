@@ -52,7 +52,7 @@ class DecoderOracle:
     def embed(self, ids) -> torch.Tensor:
         return self.W["embed_tokens.weight"][torch.as_tensor(ids, dtype=torch.long)]
 
-    def forward(self, h: torch.Tensor, last_only: bool = True) -> torch.Tensor:
+    def forward(self, h: torch.Tensor, last_only: bool = True, keep_from: int = None) -> torch.Tensor:
         """h (T, hidden) bf16-valued float32; appends to the cache at
         self.offset and advances it.  Returns bf16-valued logits (T or 1, V)
         (decoder.py:243-253; the reference computes every position, only the
@@ -95,7 +95,9 @@ class DecoderOracle:
             act = bf(gt * torch.sigmoid(gt) * up)
             h = bf(h + bf(act @ W[p + "mlp.down_proj.weight"].T))
         self.offset += T
-        if last_only:
+        if keep_from is not None:               # teacher-forced checks: logits of rows keep_from.. only
+            h = h[keep_from:]
+        elif last_only:
             h = h[-1:]
         x = rms_norm(h, W["norm.weight"], self.eps)
         return bf(x @ W["embed_tokens.weight"].T)

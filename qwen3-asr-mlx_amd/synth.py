@@ -18,9 +18,11 @@ def small_config() -> ModelConfig:
     )
 
 
-def random_state(cfg: ModelConfig, seed: int = 0, device="cpu", bias_std: float = 0.0, norm_jitter: float = 0.0) -> dict:
+def random_state(cfg: ModelConfig, seed: int = 0, device="cpu", bias_std: float = 0.0, norm_jitter: float = 0.0,
+                 embed_std: float = 0.02) -> dict:
     """Checkpoint-keyed tensors (bf16).  bias_std / norm_jitter > 0 make biases and norm weights
-    non-trivial so tests exercise them."""
+    non-trivial so tests exercise them; embed_std widens the logit spread of the tied head
+    (logit std = embed_std * sqrt(hidden_size) for a unit-RMS final hidden state)."""
     import torch
     g = torch.Generator(device=device).manual_seed(seed)
     a, t = cfg.audio_encoder, cfg.text_decoder
@@ -56,7 +58,7 @@ def random_state(cfg: ModelConfig, seed: int = 0, device="cpu", bias_std: float 
     lin("audio_tower.proj1", a.d_model, a.d_model, True)
     lin("audio_tower.proj2", a.output_dim, a.d_model, True)
 
-    st["model.embed_tokens.weight"] = (torch.randn(t.vocab_size, t.hidden_size, generator=g, device=device) * 0.02).to(torch.bfloat16)
+    st["model.embed_tokens.weight"] = (torch.randn(t.vocab_size, t.hidden_size, generator=g, device=device) * embed_std).to(torch.bfloat16)
     qd, kd = t.num_attention_heads * t.head_dim, t.num_key_value_heads * t.head_dim
     for i in range(t.num_hidden_layers):
         p = f"model.layers.{i}."

@@ -559,11 +559,60 @@ def test_run_sharded_over_rccl_world1(dev, small):
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        got = qd.run_sharded(lambda a, m: model.generate_tokens(a, m, "English"), xs, budgets, device=dev)
+        run = lambda a, n, m: model.generate_tokens_packed(a, n, m, "English")      # noqa: E731 -- padded device tensor + lengths
+        got = qd.run_sharded(run, xs, budgets, device=dev)
+        from qwen3_asr_mlx_amd.audio import pack_audio
+        packed, _, lens = pack_audio(xs, dev)                                 # request already resident in HBM (bench.py's form)
+        got_resident = qd.run_sharded(run, (packed, lens), budgets, device=dev)
     finally:
         if created:
             dist.destroy_process_group()
-    assert got == want
+    assert got == want and got_resident == want
+
+
+def test_front_door_fails_fast_after_worker_death(dev, small, monkeypatch):
+    """once the row worker has died, queued and later requests must fail instead of hanging."""
+    from qwen3_asr_mlx_amd import generate as gen
+    from qwen3_asr_mlx_amd.serve import ContinuousTranscriber
+    cfg, state, model = small
+    calls = {"n": 0}
+    real_run = gen.RowScheduler.run
+
+    def flaky(self):
+        calls["n"] += 1
+        if calls["n"] >= 2:
+            raise RuntimeError("injected decode failure")
+        return real_run(self)
+    monkeypatch.setattr(gen.RowScheduler, "run", flaky)
+    srv = ContinuousTranscriber(model, rows=2, chunk_duration=2.0, max_new_tokens=300, min_admit=1, check_every=2)
+    futs = [srv.submit(signal("speechlike", 16000 + 500 * i, seed=900 + i), max_tokens=40) for i in range(6)]
+    for f in futs:                                                            # rows, waiting-for-a-row, encoded queue, raw queue
+        with pytest.raises(RuntimeError, match="injected decode failure"):
+            f.result(timeout=60)
+    with pytest.raises(RuntimeError, match="has failed"):
+        srv.submit(signal("noise", 16000))
+    with pytest.raises(RuntimeError, match="injected decode failure"):
+        srv.close()
+
+
+def test_graph_is_recaptured_when_the_cache_is_recreated(dev, small):
+    """the captured step bakes the attention workspace's address too.  Evict the lane's caches, come back to the
+    first geometry with a context over 1,024 tokens (the chunked attention path that uses the workspace): graph == eager."""
+    cfg, state, model = small
+    dec = model._decoder
+    x = signal("speechlike", 16000 * 70, seed=77)                            # 70 s: 910 audio tokens + prompt, 200 new -> > 1,024
+    first = model.generate_tokens([x], [200], "English")[0]
+    for n in (3, 5, 7):                                                      # three other geometries: batch_cache evicts
+        model.generate_tokens([signal("noise", 16000 * n, seed=n)], [4], "English")
+    junk = [torch.empty((1 << k,), dtype=torch.float32, device=dev) for k in range(8, 20)]   # perturb the small-block pool
+    again = model.generate_tokens([x], [200], "English")[0]
+    del junk
+    model.use_graph = False
+    try:
+        eager = model.generate_tokens([x], [200], "English")[0]
+    finally:
+        model.use_graph = True
+    assert first == again == eager
 
 
 def test_full_size_encoder_bit_identical_beside_decode_on_another_lane(dev, full):

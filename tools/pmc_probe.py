@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Minimal program for `rocprofv3 --pmc ...` / `--kernel-trace --stats` runs (placed directly after `--`): no helper
+threads, no side streams, no graph capture unless asked for.  Runs, eagerly, on the legacy-free current stream:
+
+  decode   3 x the weight-streaming GEMM launches of one batch-32 decode step (decoder.gemm_only_step)
+  step     2 x one whole eager decode step at batch 32 (adds attention, residual+norm, sampling)
+  encoder  one mel + encoder pass over 32 x 30 s clips
+  prefill  one prefill of those 32 prompts
+  batch1   4 eager decode steps at batch 1 (the fused residual+norm GEMM path, 144 KiB of dynamic LDS)
+  graph    capture the batch-32 decode step into a hipGraph and replay it 4 times
+  graph4   the same with the 4-step graph
+
+Usage: python3 tools/pmc_probe.py decode,encoder [--batch 32] [--seconds 30]
+Writes gpurun_out/pmc_probe_meta.json: sha-256 (first 16 hex) of the library that ran, and what ran."""
+import hashlib
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import qwen3_asr_mlx_amd as q  # noqa: E402
+from qwen3_asr_mlx_amd import _lib, synth  # noqa: E402
+from qwen3_asr_mlx_amd.config import ModelConfig  # noqa: E402
+from qwen3_asr_mlx_amd.generate import _merge  # noqa: E402
+from qwen3_asr_mlx_amd.tokenizer import build_prompt  # noqa: E402
+from signals import signal  # noqa: E402
+
+what = set((sys.argv[1] if len(sys.argv) > 1 else "decode,encoder").split(","))
+B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 32
+secs = float(sys.argv[sys.argv.index("--seconds") + 1]) if "--seconds" in sys.argv else 30.0
+dev = torch.device("cuda:0")
+cfg = ModelConfig()
+model = q.Qwen3ASR.from_state_dict(cfg, synth.random_state(cfg, seed=0, device=dev), synth.SyntheticTokenizer(), dev)
+dec, enc = model._decoder, model._encoder
+t0 = time.perf_counter()
+
+
+def say(msg):
+    print(f"[probe {time.perf_counter() - t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+sampling = {"temperature": 0.0, "top_p": 1.0, "top_k": 0, "repetition_penalty": 1.2, "repetition_context_size": 100, "seed": 0}
+n = int(secs * 16000)
+feats = counts = None
+if what & {"encoder", "prefill", "step", "graph", "graph4", "batch1"}:
+    audio, lens_dev, lens = q.audio.pack_audio([signal("speechlike", n, seed=1234 + i) for i in range(B)], dev)
+    mel, n_frames = q.audio.get_frontend(dev)(audio, lens_dev, lens)
+    feats, counts = enc.forward_batch(mel, n_frames)
+    torch.cuda.synchronize()
+    say("encoder pass done")
+
+
+def prefilled(b):
+    prompts = [build_prompt(c, [6364]) for c in counts[:b]]
+    seq = [len(p) for p in prompts]
+    cache = dec.batch_cache(b, (max(seq) + 64 + 63) // 64 * 64)
+    ws = dec.workspace(b, 64)
+    ws.n_gen.zero_(); ws.finished.zero_()
+    ws.pos.copy_(torch.tensor([t - 1 for t in seq], dtype=torch.int32))
+    ws.max_new.copy_(torch.tensor([64] * b, dtype=torch.int32))
+    emb = _merge(feats[: sum(counts[:b])], prompts, counts[:b], dec)
+    dec.prefill(emb, seq, cache, logits_out=ws.logits)
+    dec.sample_step(ws, ws.logits, sampling)
+    torch.cuda.synchronize()
+    return ws, cache
+
+
+if "decode" in what:
+    ws = dec.workspace(B, 64)
+    for _ in range(3):
+        dec.gemm_only_step(ws)
+    torch.cuda.synchronize()
+    say("decode GEMMs done")
+if what & {"prefill", "step", "graph", "graph4"}:
+    ws, cache = prefilled(B)
+    say("prefill done")
+    if "step" in what:
+        for _ in range(2):
+            dec.decode_step(ws, cache, sampling)
+        torch.cuda.synchronize()
+        say("eager decode steps done")
+    for name, steps in (("graph", 1), ("graph4", dec.MULTI_STEPS)):
+        if name in what:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dec.decode_step(ws, cache, sampling)
+                g = dec._capture(ws, cache, sampling, steps)
+                for _ in range(4):
+                    _lib.call("q3asr_graph_launch", g, torch.cuda.current_stream().cuda_stream)
+                side.synchronize()
+                _lib.call("q3asr_graph_destroy", g)
+            say(f"{name}: captured and replayed")
+if "batch1" in what:
+    ws1, cache1 = prefilled(1)
+    for _ in range(4):
+        dec.decode_step(ws1, cache1, sampling)
+    torch.cuda.synchronize()
+    say("batch-1 eager steps (fused residual+norm GEMM) done")
+out = ROOT / "gpurun_out"
+out.mkdir(exist_ok=True)
+(out / "pmc_probe_meta.json").write_text(json.dumps({
+    "lib_sha16": hashlib.sha256(_lib.LIB_PATH.read_bytes()).hexdigest()[:16], "ran": sorted(what), "batch": B, "clip_seconds": secs}))
+say("done")
