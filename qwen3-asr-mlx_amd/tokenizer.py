@@ -49,9 +49,10 @@ def _load_backend(root: Path):
     vocab_file, merges_file = root / "vocab.json", root / "merges.txt"
     if not (vocab_file.exists() and merges_file.exists()):
         raise FileNotFoundError(f"No tokenizer.json or vocab.json+merges.txt found in {root}")
-    rows = [ln for ln in merges_file.read_text(encoding="utf-8").splitlines() if ln.strip()]
-    if rows and rows[0].startswith("#"):
-        rows.pop(0)
+    rows = merges_file.read_text(encoding="utf-8").splitlines()
+    if rows and rows[0].startswith("#"):                      # "#version: 0.2" header, only as the very first line
+        rows = rows[1:]
+    rows = [r for r in rows if r.strip()]
     tok = hf.Tokenizer(hf.models.BPE(vocab=json.loads(vocab_file.read_text(encoding="utf-8")), merges=[tuple(r.split()) for r in rows]))
     tok.pre_tokenizer = hf.pre_tokenizers.ByteLevel(add_prefix_space=False)
     tok.decoder = hf.decoders.ByteLevel()

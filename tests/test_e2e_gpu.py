@@ -425,6 +425,41 @@ def test_decode_v1_and_v3_agree(dev, small):
     assert v1[0] == v3[0] and agree >= 16
 
 
+def test_real_checkpoint_harness_plumbing(dev, tmp_path, capsys):
+    """tools/check_real_checkpoint.py on a synthetic model directory and a reference file made from this package's own
+    outputs: exercises the harness end to end (from_pretrained, WAV loading, token comparison, `first_logits_top5`
+    consumption).  It proves the harness works, not parity with MLX (no MLX outputs exist in this pipeline)."""
+    import json
+    import struct
+    import check_real_checkpoint as crc
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    d = synth.write_model_dir(tmp_path / "m", synth.small_config(), seed=6, bias_std=0.02, norm_jitter=0.1)
+    model = q.Qwen3ASR.from_pretrained(d, device=dev)
+    items = []
+    for i, n in enumerate((16000, 40000)):
+        x = signal("speechlike", n, seed=950 + i)
+        pcm = np.clip(np.round(x * 32767.0), -32768, 32767).astype("<i2").tobytes()
+        fmt = struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(pcm)) + pcm
+        (tmp_path / f"a{i}.wav").write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+        s = q.load_audio(tmp_path / f"a{i}.wav")
+        toks = model.generate_tokens([s], [max(256, int(len(s) / 16000 * 50))], "English", repetition_penalty=1.2)[0]
+        lg = crc.first_logits(model, s, "English")
+        top = torch.topk(lg, 5)
+        items.append({"audio": f"a{i}.wav", "language": "en", "tokens": toks, "text": model._decode_output(toks),
+                      "first_logits_top5": [[int(a), float(b)] for a, b in zip(top.indices, top.values)]})
+    (tmp_path / "ref.json").write_text(json.dumps(items))
+    assert crc.main([str(d), str(tmp_path / "ref.json")]) == 0
+    assert "2/2 utterances token-identical; 2/2 first-position logit checks passed" in capsys.readouterr().out
+    items[1]["tokens"][3] = (items[1]["tokens"][3] + 1) % 1000
+    items[0]["first_logits_top5"][0][1] += 1.0                               # a logit 1.0 off must fail the check
+    (tmp_path / "ref.json").write_text(json.dumps(items))
+    assert crc.main([str(d), str(tmp_path / "ref.json")]) == 1
+    out = capsys.readouterr().out
+    assert "diverges at token 3" in out and "1/2 utterances token-identical; 1/2 first-position logit checks passed" in out
+
+
 # ----------------------------------------------------------------------------- BASELINE.json configs[4]: fp8 weights, long-form, sampling
 def _effective_state(state, cfg):
     """Checkpoint with the decoder projections / embedding replaced by their fp8-dequantised values."""

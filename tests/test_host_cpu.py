@@ -127,6 +127,32 @@ def test_wav_reader_and_resampler(tmp_path):
     assert np.array_equal(load_audio(tmp_path / "f.wav", target_sr=sr), x)
 
 
+def test_load_audio_matches_live_reference_fixtures(tmp_path):
+    """f2 pinned: WAV images (PCM16 stereo / 3 channels, PCM32, float32, a foreign chunk before the data, an 18-byte fmt, a
+    truncated last frame, 8 k / 22.05 k / 44.1 k -> 16 k and 48 k -> 8 k) and the arrays the LIVE reference loader returned for
+    them (tools/gen_golden.py, reference audio.py:103-204): bit-exact.  The RIFF fast path's exceptions match too."""
+    from qwen3_asr_mlx_amd import load_audio
+    from qwen3_asr_mlx_amd.audio import _read_wav_pcm
+    fx = np.load(GOLD / "load_audio.npz")
+    meta = json.loads((GOLD / "load_audio.json").read_text())
+    good = [k for k in meta if not k.startswith("bad_")]
+    assert len(good) >= 10
+    for name in good:
+        f = tmp_path / f"{name}.wav"
+        f.write_bytes(fx[name + "__wav"].tobytes())
+        got = load_audio(f, target_sr=meta[name]["target_sr"])
+        want = fx[name + "__out"]
+        assert got.dtype == np.float32 and got.shape == want.shape == (meta[name]["n_out"],), name
+        assert np.array_equal(got, want), name
+    for name in (k for k in meta if k.startswith("bad_")):
+        f = tmp_path / f"{name}.wav"
+        f.write_bytes(fx[name + "__wav"].tobytes())
+        assert meta[name]["raises"] is not None
+        with pytest.raises(Exception) as ei:
+            _read_wav_pcm(f)
+        assert type(ei.value).__name__ == meta[name]["raises"] and str(ei.value) == meta[name]["message"], name
+
+
 def test_encoder_plan_and_masks_cpu():
     """Host-side batch plan: chunk table, pad-strip row map, attention windows per utterance."""
     import torch
@@ -199,3 +225,99 @@ def test_library_is_built_without_packed_fp32_instructions(tmp_path):
         assert not hits, f"{o.name}: packed fp32 instructions in the shipped code object: {hits[:3]}"
         n_mfma += dis.count("v_mfma_f32_16x16x32_bf16")
     assert n_mfma > 100                     # the disassembly really is the gfx950 device code
+
+
+# ----------------------------------------------------------------------------- f1: loader hardening (reference encoder.py:346-358, decoder.py:279-290, tokenizer.py:124-152)
+def test_strict_weight_loading_rejects_missing_and_extra_keys():
+    """MLX `load_weights` is strict: a checkpoint with a missing or an unknown tensor must not load."""
+    import torch
+    from qwen3_asr_mlx_amd import synth
+    from qwen3_asr_mlx_amd.decoder import TextDecoder
+    from qwen3_asr_mlx_amd.encoder import AudioEncoder
+    cfg = synth.small_config()
+    st = synth.random_state(cfg, seed=1)
+    enc_w = {k[len("audio_tower."):]: v for k, v in st.items() if k.startswith("audio_tower.")}
+    dec_w = {k[len("model."):]: v for k, v in st.items() if k.startswith("model.")}
+    AudioEncoder(cfg.audio_encoder).load_state(dict(enc_w), "cpu")                    # the complete set loads
+    TextDecoder(cfg.text_decoder).load_state(dict(dec_w), "cpu")
+    for drop in ("conv2d2.bias", "layers.1.fc2.weight", "ln_post.weight", "conv_out.weight"):
+        w = dict(enc_w)
+        del w[drop]
+        with pytest.raises(ValueError, match="missing"):
+            AudioEncoder(cfg.audio_encoder).load_state(w, "cpu")
+    with pytest.raises(ValueError, match="extra"):
+        AudioEncoder(cfg.audio_encoder).load_state({**enc_w, "layers.2.fc1.weight": torch.zeros(1)}, "cpu")
+    with pytest.raises(ValueError, match="extra"):
+        AudioEncoder(cfg.audio_encoder).load_state({**enc_w, "conv_out.bias": torch.zeros(1)}, "cpu")       # conv_out has no bias
+    for drop in ("embed_tokens.weight", "norm.weight", "layers.0.self_attn.q_norm.weight", "layers.1.mlp.down_proj.weight"):
+        w = dict(dec_w)
+        del w[drop]
+        with pytest.raises(ValueError, match="missing"):
+            TextDecoder(cfg.text_decoder).load_state(w, "cpu")
+    with pytest.raises(ValueError, match="extra"):
+        TextDecoder(cfg.text_decoder).load_state({**dec_w, "lm_head.weight": torch.zeros(1)}, "cpu")        # the head is tied
+    with pytest.raises(ValueError, match="weight_dtype"):
+        TextDecoder(cfg.text_decoder).load_state(dict(dec_w), "cpu", weight_dtype="int4")
+
+
+def test_tokenizer_loads_from_both_file_layouts(tmp_path):
+    """tokenizer.json, or vocab.json + merges.txt (with and without the '#version' header line); neither -> FileNotFoundError."""
+    from tokenizers import Tokenizer as HFTokenizer, decoders, models, pre_tokenizers
+    from qwen3_asr_mlx_amd import Tokenizer
+    alphabet = sorted(pre_tokenizers.ByteLevel.alphabet())
+    vocab = {ch: i for i, ch in enumerate(alphabet)}
+    sp = "\u0120"                                                       # byte-level space
+    merges = [("h", "e"), ("l", "l"), ("he", "ll"), (sp, "w"), ("hell", "o")]
+    for a, b in merges:
+        vocab[a + b] = len(vocab)
+    tok = HFTokenizer(models.BPE(vocab=vocab, merges=merges))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    a = tmp_path / "single"
+    a.mkdir()
+    tok.save(str(a / "tokenizer.json"))
+    text = "hello world, hello"
+    want = tok.encode(text).ids
+    assert Tokenizer(a).encode(text) == want and vocab["hello"] in want
+    for name, header in (("pair_header", "#version: 0.2\n"), ("pair_plain", "")):
+        d = tmp_path / name
+        d.mkdir()
+        (d / "vocab.json").write_text(json.dumps(vocab), encoding="utf-8")
+        (d / "merges.txt").write_text(header + "\n".join(f"{x} {y}" for x, y in merges) + "\n\n", encoding="utf-8")
+        t = Tokenizer(d)
+        assert t.encode(text) == want and t.decode(want) == text
+        assert t.build_prompt(3, "English")[:9] == [151644, 8948, 198, 151645, 198, 151644, 872, 198, 151669]
+    (tmp_path / "empty").mkdir()
+    with pytest.raises(FileNotFoundError, match="tokenizer.json"):
+        Tokenizer(tmp_path / "empty")
+    (tmp_path / "empty" / "vocab.json").write_text("{}")                  # vocab without merges is not enough
+    with pytest.raises(FileNotFoundError):
+        Tokenizer(tmp_path / "empty")
+
+
+def test_mlx_conv_layout_maps_to_time_major_taps_at_full_conv_shapes():
+    """Checkpoint conv weights are (O, kH=freq, kW=time, I) (MLX nn.Conv2d; reference encoder.py:155-168); the HIP conv stem
+    wants tap order (time, freq) with the input channel fastest, conv_out its input reordered from ch*freq+f to f*C+ch
+    (encoder.py:278).  Checked element by element at the 1.7B conv shapes (480 channels, 16 frequency rows, d_model 1024)."""
+    import torch
+    from qwen3_asr_mlx_amd import synth
+    from qwen3_asr_mlx_amd.config import AudioEncoderConfig, ModelConfig
+    from qwen3_asr_mlx_amd.encoder import AudioEncoder
+    full = AudioEncoderConfig()
+    assert (full.downsample_hidden_size, full.d_model, full.num_mel_bins) == (480, 1024, 128)
+    cfg = ModelConfig(audio_encoder=AudioEncoderConfig(encoder_layers=1))            # conv stem + conv_out at full size, one layer
+    st = synth.random_state(cfg, seed=4)
+    W = {k[len("audio_tower."):]: v for k, v in st.items() if k.startswith("audio_tower.")}
+    enc = AudioEncoder(cfg.audio_encoder)
+    enc.load_state(dict(W), "cpu")
+    C = 480
+    w2, w3 = W["conv2d2.weight"].float(), W["conv2d3.weight"].float()
+    assert w2.shape == (C, 3, 3, C) and W["conv2d1.weight"].shape == (C, 3, 3, 1) and W["conv_out.weight"].shape == (1024, C * 16)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(200):
+        o, kf, kt, i = (int(torch.randint(0, n, (1,), generator=g)) for n in (C, 3, 3, C))
+        assert float(enc.w["c2_w"][o, (kt * 3 + kf) * C + i]) == float(w2[o, kf, kt, i])
+        assert float(enc.w["c3_w"][o, (kt * 3 + kf) * C + i]) == float(w3[o, kf, kt, i])
+        assert float(enc.w["c1_w"][o, kt, kf]) == float(W["conv2d1.weight"][o, kf, kt, 0])
+        d, f = int(torch.randint(0, 1024, (1,), generator=g)), int(torch.randint(0, 16, (1,), generator=g))
+        assert float(enc.w["co_w"][d, f * C + i]) == float(W["conv_out.weight"][d, i * 16 + f])

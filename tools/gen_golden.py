@@ -80,6 +80,43 @@ def signal(kind: str, n: int) -> np.ndarray:
     raise ValueError(kind)
 
 
+def wav_bytes(tag: int, bits: int, channels: int, rate: int, payload: bytes, extra_chunk: bytes = b"", odd_pad: bool = False,
+              fmt_extra: bytes = b"") -> bytes:
+    """A RIFF/WAVE image: fmt chunk (optionally with extension bytes), an optional foreign chunk BEFORE the data, data."""
+    import struct
+    fmt = struct.pack("<HHIIHH", tag, channels, rate, rate * channels * bits // 8, channels * bits // 8, bits) + fmt_extra
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + extra_chunk + b"data" + struct.pack("<I", len(payload)) + payload
+    if odd_pad:
+        body += b"\x00"
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def wav_cases() -> dict:
+    """name -> (wav bytes, target_sr): PCM16 stereo, PCM32, float32, a foreign chunk, 8 k / 44.1 k / 22.05 k -> 16 k, a
+    truncated last frame, WAVE_FORMAT_EXTENSIBLE-length fmt, 3 channels."""
+    import struct
+    rng = np.random.default_rng(77)
+    t = np.arange(4410) / 44100.0
+    x = (0.4 * np.sin(2 * np.pi * 330.0 * t) + 0.05 * rng.standard_normal(len(t))).astype(np.float32)
+    i16 = lambda v: np.clip(np.round(v * 32767.0), -32768, 32767).astype("<i2")          # noqa: E731
+    i32 = lambda v: np.clip(np.round(v.astype(np.float64) * 2147483647.0), -2147483648, 2147483647).astype("<i4")  # noqa: E731
+    st = np.stack([i16(x), i16(x[::-1])], axis=1).reshape(-1)
+    three = np.stack([i16(x), i16(0.5 * x), i16(-0.25 * x)], axis=1).reshape(-1)
+    lst = b"LIST" + struct.pack("<I", 6) + b"abcdef"
+    return {
+        "pcm16_stereo_44k": (wav_bytes(1, 16, 2, 44100, st.tobytes()), 16000),
+        "pcm16_mono_16k": (wav_bytes(1, 16, 1, 16000, i16(x[:1600]).tobytes()), 16000),
+        "pcm32_mono_8k": (wav_bytes(1, 32, 1, 8000, i32(x[:800]).tobytes()), 16000),
+        "f32_mono_22k": (wav_bytes(3, 32, 1, 22050, x[:2205].tobytes()), 16000),
+        "f32_stereo_16k_list_chunk": (wav_bytes(3, 32, 2, 16000, np.stack([x[:900], -x[:900]], 1).reshape(-1).tobytes(), extra_chunk=lst), 16000),
+        "pcm16_3ch_8k": (wav_bytes(1, 16, 3, 8000, three[: 3 * 801].tobytes()), 16000),
+        "pcm16_stereo_truncated_frame": (wav_bytes(1, 16, 2, 16000, st[:2001].tobytes()), 16000),       # odd sample count: last frame dropped
+        "pcm16_mono_fmt18": (wav_bytes(1, 16, 1, 16000, i16(x[:700]).tobytes(), fmt_extra=b"\x00\x00"), 16000),
+        "pcm16_mono_48k_to_8k": (wav_bytes(1, 16, 1, 48000, i16(x[:4800]).tobytes()), 8000),
+        "f32_mono_16k_same_rate": (wav_bytes(3, 32, 1, 16000, x[:333].tobytes(), odd_pad=True), 16000),
+    }
+
+
 def main() -> None:
     OUT.mkdir(parents=True, exist_ok=True)
     audio = _load_ref_audio()
@@ -119,6 +156,32 @@ def main() -> None:
         full[f"noise_n{n}"] = mel
     np.savez_compressed(OUT / "mel_full.npz", **full)
     (OUT / "mel_digest.json").write_text(json.dumps(digest))
+
+    # ---- audio files through the live reference loader (audio.py:103-204): the WAV images and what it returns
+    import tempfile
+    arrs, meta = {}, {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, (img, target) in wav_cases().items():
+            f = Path(td) / f"{name}.wav"
+            f.write_bytes(img)
+            got = audio.load_audio(f, target_sr=target)
+            assert got.dtype == np.float32 and got.ndim == 1
+            arrs[name + "__wav"] = np.frombuffer(img, dtype=np.uint8)
+            arrs[name + "__out"] = got
+            meta[name] = {"target_sr": target, "n_out": int(len(got)), "sha256": hashlib.sha256(got.tobytes()).hexdigest()}
+        bad = {"not_riff": b"RIFX" + b"\x00" * 40, "no_data": wav_bytes(1, 16, 1, 16000, b"")[:36],
+               "adpcm": wav_bytes(2, 4, 1, 16000, b"\x00" * 64), "pcm24": wav_bytes(1, 24, 1, 16000, b"\x00" * 48)}
+        for name, img in bad.items():                      # what the RIFF fast path raises (it is then swallowed by load_audio)
+            f = Path(td) / f"{name}.wav"
+            f.write_bytes(img)
+            try:
+                audio._read_wav_pcm(f)
+                meta["bad_" + name] = {"raises": None}
+            except Exception as e:                          # noqa: BLE001
+                meta["bad_" + name] = {"raises": type(e).__name__, "message": str(e)}
+            arrs["bad_" + name + "__wav"] = np.frombuffer(img, dtype=np.uint8)
+    np.savez_compressed(OUT / "load_audio.npz", **arrs)
+    (OUT / "load_audio.json").write_text(json.dumps(meta, indent=1))
 
     # ---- raw STFT power for one short signal (audio.py:211-235, :266)
     x = signal("noise", 8000)

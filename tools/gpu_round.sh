@@ -1,0 +1,45 @@
+#!/bin/bash
+# One gpurun call = a list of steps, each bounded by its own timeout; a step that is killed (timeout, signal) ends the call
+# (no GPU step is started after a killed one).  Usage: tools/gpu_round.sh <tag> step [step ...]
+#   tests | tests_parity | bench | pmc | mfma | stats | probe_batch1 | probe_graph | probe_graph4
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+TAG=$1; shift
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+run() {   # run <seconds> <logfile> cmd...
+    local secs=$1 log=$2; shift 2
+    echo "== $(date +%T) $*" | tee -a $O/${TAG}_steps.log
+    timeout -k 10 $secs "$@" > $log 2>&1
+    local rc=$?
+    echo "   rc=$rc" | tee -a $O/${TAG}_steps.log
+    if [ $rc -eq 124 ] || [ $rc -ge 128 ]; then echo "step killed (rc=$rc): stopping this call" | tee -a $O/${TAG}_steps.log; tail -30 $log; exit $rc; fi
+    return 0
+}
+prof() {  # prof <name> <probe list> <rocprofv3 args...>
+    local name=$1 what=$2; shift 2
+    rm -rf $O/${TAG}_$name
+    run 420 $O/${TAG}_$name.log rocprofv3 "$@" --output-format csv -d $O/${TAG}_$name -- python3 $R/tools/pmc_probe.py $what
+    find $O/${TAG}_$name -name '*.csv' -size +20M -delete          # keep the merge-back under the 64 MiB cap
+}
+for step in "$@"; do
+    case $step in
+    tests)        run 900 $O/${TAG}_tests.log python3 -m pytest $R/tests -m gpu -q -x --deselect $R/tests/test_parity_gpu.py ; tail -5 $O/${TAG}_tests.log ;;
+    tests_parity) run 900 $O/${TAG}_parity.log python3 -m pytest $R/tests/test_parity_gpu.py -m gpu -q -s ; tail -15 $O/${TAG}_parity.log ;;
+    tests_all)    run 1100 $O/${TAG}_tests_all.log python3 -m pytest $R/tests -m gpu -q -x ; tail -5 $O/${TAG}_tests_all.log ;;
+    bench)        run 600 $O/${TAG}_bench.err python3 $R/bench.py --steps 20 --warmup 3 ; grep '^{' $O/${TAG}_bench.err > $O/${TAG}_bench.json; grep -v '^{' $O/${TAG}_bench.err | tail -25 ;;
+    benchq)       run 400 $O/${TAG}_benchq.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchq.err > $O/${TAG}_benchq.json; grep -v '^{' $O/${TAG}_benchq.err | tail -12 ;;
+    pmc)          prof pmc_fetch decode,encoder,prefill --pmc FETCH_SIZE --kernel-trace
+                  prof pmc_write decode,encoder,prefill --pmc WRITE_SIZE --kernel-trace
+                  python3 $R/tools/pmc_summary.py $(find $O/${TAG}_pmc_fetch -name '*counter_collection.csv') $(find $O/${TAG}_pmc_write -name '*counter_collection.csv') $O/${TAG}_pmc_summary.json $O/pmc_probe_meta.json > $O/${TAG}_pmc_print.txt 2>&1; tail -20 $O/${TAG}_pmc_print.txt ;;
+    mfma)         prof mfma encoder,prefill --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace
+                  python3 $R/tools/mfma_util.py $(find $O/${TAG}_mfma -name '*counter_collection.csv') $(find $O/${TAG}_mfma -name '*kernel_trace.csv') $O/${TAG}_mfma_util.json > $O/${TAG}_mfma_print.txt 2>&1; tail -16 $O/${TAG}_mfma_print.txt ;;
+    stats)        prof stats decode,encoder,prefill,step --kernel-trace --stats
+                  find $O/${TAG}_stats -name '*kernel_stats.csv' -exec head -30 {} \; ;;
+    probe_batch1) prof probe_batch1 batch1 --pmc FETCH_SIZE --kernel-trace ;;
+    probe_graph)  prof probe_graph graph --pmc FETCH_SIZE --kernel-trace ;;
+    probe_graph4) prof probe_graph4 graph4 --pmc FETCH_SIZE --kernel-trace ;;
+    *) echo "unknown step $step" ;;
+    esac
+done
+echo "== done" | tee -a $O/${TAG}_steps.log
