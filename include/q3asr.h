@@ -40,7 +40,8 @@ int q3asr_conv1_gelu(const float* mel, int Fmax, const int32_t* chunk_b, const i
                      const float* w9, const float* bias, void* out, int C1, void* stream);
 
 /* ---- encoder.py:274-275  conv2d2 / conv2d3 (+GELU) as implicit GEMM --------------------------
- * x bf16 [imgs][Hin][Win][Cin]; w bf16 [Cout][3][3][Cin] (tap order = x's spatial dims);
+ * x bf16 [imgs][Hin][Win][Cin]; w bf16 in chunk-major K order [Cout][ceil(Cin/64)][9 taps][64] (tap = 3*kh + kw over
+ * x's two spatial dims, zero channels beyond Cin: the nine taps of a 64-channel chunk are consecutive K tiles);
  * out row m = (img*Hout + oh)*Wout + ow (or row_map[m], <0 = skip); act: 0 none, 1 GELU;
  * out_kind: 0 bf16, 1 fp32. */
 int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, int Cin, const void* w, int Cout,

@@ -34,26 +34,25 @@ __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }          // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
 __device__ __forceinline__ float round_bf(float x) { return (float)(bf16)x; }
 
-// exact-erf GELU (MLX nn.gelu; encoder.py:118,273-275,320): x * Phi(x) with Phi from the complementary error function in
-// Chebyshev-fitted form erfc(z) = t exp(-z^2 + P(t)), t = 1 / (1 + z/2), z >= 0 -- fractional error < 1.2e-7 everywhere
-// (Numerical Recipes erfcc), so the negative tail keeps relative accuracy, which 1 + erf(.) would lose; branch-free, one
-// reciprocal and one exponential (the library erff costs about three times as many instructions and the GELU epilogues of
-// conv1 / conv2 / conv3 / fc1 are VALU-bound).  Outputs are rounded to bf16 by every caller.
+// exact-erf GELU (MLX nn.gelu; encoder.py:118,273-275,320): x * Phi(x), Phi(-|x|) = erfc(|x| / sqrt 2) / 2 with erfc from
+// Abramowitz & Stegun 7.1.26, erfc(z) = (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z), |error| <= 1.5e-7 absolute
+// (about one fp32 ulp of an O(1) output; every caller rounds to bf16, 2^-8 relative).  The product form keeps relative
+// accuracy in the negative tail, which 1 + erf(.) would lose.  15 VALU instructions, two of them transcendental (one
+// reciprocal, one exp2 with the scale folded into the argument): the epilogues of conv1 / conv2 / conv3 / fc1 are
+// VALU-bound on this function (the Numerical Recipes erfcc form used before cost 21: fc1 149 -> see profiles/README.md).
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.5f * z);            // v_rcp_f32 (1 ulp): inside the fit's 1.2e-7
-    float p = 0.17087277f;
-    p = fmaf(p, t, -0.82215223f);
-    p = fmaf(p, t, 1.48851587f);
-    p = fmaf(p, t, -1.13520398f);
-    p = fmaf(p, t, 0.27886807f);
-    p = fmaf(p, t, -0.18628806f);
-    p = fmaf(p, t, 0.09678418f);
-    p = fmaf(p, t, 0.37409196f);
-    p = fmaf(p, t, 1.00002368f);
-    p = fmaf(p, t, -1.26551223f);
-    const float half_erfc = 0.5f * t * __expf(fmaf(-z, z, p));           // Phi(-|x|)
-    return x * (x < 0.f ? half_erfc : 1.0f - half_erfc);
+    constexpr float C = 0.84932180028801904f;                 // sqrt(log2(e) / 2): u^2 = z^2 log2(e), z = |x| / sqrt 2
+    constexpr float P = 0.3275911f / 1.2011224087864498f;     // p / sqrt(log2 e): 1 + p z = 1 + P u
+    const float u = fabsf(x) * C;
+    const float t = __builtin_amdgcn_rcpf(fmaf(P, u, 1.0f));   // v_rcp_f32 (1 ulp)
+    float r = 0.5f * 1.061405429f;
+    r = fmaf(r, t, 0.5f * -1.453152027f);
+    r = fmaf(r, t, 0.5f * 1.421413741f);
+    r = fmaf(r, t, 0.5f * -0.284496736f);
+    r = fmaf(r, t, 0.5f * 0.254829592f);
+    const float half_erfc = r * t * __builtin_amdgcn_exp2f(-(u * u));   // Phi(-|x|)
+    const float xh = x * half_erfc;
+    return x < 0.f ? xh : x - xh;
 }
 
 // ---- wave reductions (wave = 64 lanes) -----------------------------------

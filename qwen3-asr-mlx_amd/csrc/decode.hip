@@ -531,7 +531,15 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_o
 // Chunks past the sequence's length exit at once: the grid is sized for the cache capacity because the
 // launch is captured in a graph while positions advance.
 // ---------------------------------------------------------------------------
+// Chunk = the unit of the reduction tree (a function of the sequence only, never of the batch or the launch geometry, so
+// results are bit-identical for any batch / cache capacity / chunks-per-workgroup choice).  1,024 tokens.  A workgroup
+// that owns all chunks of its sequence keeps the per-chunk partials in LDS (same merge, same order, no workspace trip).
+// Tried (round 2): 256-token chunks, one per workgroup at small batch (24 workgroups instead of 8 for a batch-1 step at
+// a 500-token context): batch-1 latency 180.5 vs 180.0 ms -- the dependent chain (slab sum -> QK-norm -> RoPE -> one tile
+// per wave -> merge) is what a batch-1 launch costs, and the cross-workgroup merge adds a ticket round trip -- and the
+// batch-32 step lost 3.7 % to the extra per-chunk barriers.
 #define ADF_CHUNK 1024
+#define ADF_LOCAL_MAX 8               // chunks whose partials fit the LDS array below
 #define ADF_PART (2 * 130)            // floats per (sequence, kv head, chunk): per head 128 numerators, max, sum
 
 // 256-byte rows of a V tile in LDS: 16-byte chunk ch of row r sits at 256 r + 16 (ch ^ f(r)); conflict-free for the row
@@ -553,6 +561,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     __shared__ float s_m[NP][2], s_l[NP][2];
     __shared__ __attribute__((aligned(16))) float s_acc[NP][2][128];
     __shared__ int s_ticket;
+    __shared__ float s_part[ADF_LOCAL_MAX][ADF_PART];                  // per-chunk partials of a workgroup that owns the whole sequence
     extern __shared__ __attribute__((aligned(16))) char adm_tiles[];   // MFMA: one 32-key V tile (8 KiB) per wave
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int pos = pos_arr[b];
@@ -560,6 +569,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     const int c_begin = blockIdx.z * G, c_end = min(c_begin + G, n_active);   // this workgroup's chunks
     if (c_begin >= n_active) return;                                  // whole workgroup: no barrier is skipped
     const int n_groups = (n_active + G - 1) / G;                      // workgroups active for this (sequence, kv head)
+    const bool local = n_groups == 1 && n_active <= ADF_LOCAL_MAX;    // uniform: partials stay in LDS, no workspace round trip
     const bool owner = c_end == n_active;                             // the last chunk holds the new token
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
@@ -718,6 +728,10 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                 }
                 if (n_active == 1) {                                      // the whole sequence is this chunk
                     out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(num / den);
+                } else if (local) {
+                    float* dst = s_part[tt / ADF_CHUNK] + h * 130;
+                    dst[d] = num;
+                    if (d == 0) { dst[128] = Mx; dst[129] = den; }
                 } else {
                     // Partials travel as device-scope (write-through) atomic stores and loads, so no cache-wide
                     // write-back or invalidate is needed.
@@ -845,6 +859,10 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                 }
                 if (n_active == 1) {
                     out16[x16_index(b, (2 * kvh + hm) * 128 + dm, MT)] = f2bf(num / den);
+                } else if (local) {
+                    float* dst = s_part[cb / ADF_CHUNK] + hm * 130;
+                    dst[dm] = num;
+                    if (dm == 0) { dst[128] = Mx; dst[129] = den; }
                 } else {
                     float* dst = mym + (long)(cb / ADF_CHUNK) * ADF_PART + hm * 130;
                     __hip_atomic_store(dst + dm, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -863,6 +881,22 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
 #undef Q3_LOAD_BATCH
     if (n_active == 1) return;                                        // uniform
     const int h = (tid >> 7) & 1, d = tid & 127;
+    if (local) {                                                      // same merge, same order, operands from LDS
+        __syncthreads();
+        if (tid < 256) {
+            float M = -INFINITY;
+            for (int c = 0; c < n_active; ++c) M = fmaxf(M, s_part[c][h * 130 + 128]);
+            float N = 0.f, D = 0.f;
+            for (int c = 0; c < n_active; ++c) {
+                const float* src = s_part[c] + h * 130;
+                const float w = __expf(src[128] - M);
+                N = fmaf(src[d], w, N);
+                D = fmaf(src[129], w, D);
+            }
+            out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(N / D);
+        }
+        return;
+    }
     float* my = part + (((long)b * nkv + kvh) * nc) * ADF_PART;
     // Each wave waits for its own partial stores to be acknowledged, the barrier collects the waves, and only
     // then is the ticket taken; the last workgroup to arrive merges every chunk of the sequence.

@@ -33,6 +33,7 @@ struct GemmParams {
     const void* res; int res_kind; long ldres; int res_mod;   // 0 none, 1 fp32, 2 bf16 (MLX bf16 add: round, add, round)
     void* out; int out_kind; long ldo;                        // 0 bf16, 1 fp32
     const int* row_map;      // optional destination row per m (<0: skip)
+    int lds_epi;             // 8-phase kernel: epilogue through the wave-private LDS transpose (host-checked preconditions)
 };
 
 // 128-byte rows: two rows make one 256-byte bank row, so the XOR uses row >> 1 and the row parity supplies the 4th bit:
@@ -100,6 +101,131 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Epilogue through a wave-private LDS transpose (8-phase kernel).  In the accumulator layout a lane owns 4 consecutive
+// columns of ONE row, so a direct store instruction covers 16 rows x 32 bytes: 32 such narrow stores per lane and tile made
+// the epilogue the largest fixed cost of a short-K tile (K sweep, profiles/README.md: ~15 us per 256^2 tile, store-issue
+// bound).  Here each 16-row x 64-column block of the wave's 128 x 64 output goes through 4 KiB of LDS that only this wave
+// touches (no barrier: DS operations of one wave execute in order) and leaves as whole rows: 8 lanes x 16 B per 128-byte
+// row (bf16), 16 lanes x 16 B per 256-byte row (fp32).  Bias / GELU / SwiGLU are applied before the transpose, residuals
+// (read as whole rows too) after it; arithmetic and rounding points are those of gemm_epilogue, so results are bit-identical.
+// Preconditions (checked on the host, else gemm_epilogue): N % 8 == 0, ldo / ldres multiples of 8, 16-byte aligned bases.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][8], int m_base, int n_base, int n0, int wn,
+                                                  char* st, int lane) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // lane-derived addresses are recomputed here from an opaque copy of the lane id: hoisted above the K loop they would
+    // stay live across it, and the 8-phase loop has no registers to spare (a spill there is a VMEM op in the counted queue)
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, li = lane & 15;
+    if (p.act == 2) {                                                     // SwiGLU: 16 rows x 32 output columns per block (64-byte rows)
+        const int n_out0 = (n0 >> 1) + wn * 32;
+        const int rr = lane >> 2, rc = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            char* blk = st + (i & 1) * 2048;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gt = round_bf(acc[2 * jj][i][r]);
+                    const float up = round_bf(acc[2 * jj + 1][i][r]);
+                    o[r] = f2bf(gt / (1.0f + __expf(-gt)) * up);
+                }
+                const int chunk = 2 * jj + (g >> 1);
+                *reinterpret_cast<bf16x4*>(blk + li * 64 + ((chunk ^ ((li >> 1) & 3)) << 4) + (g & 1) * 8) = o;
+            }
+            const u32x4 v = *reinterpret_cast<const u32x4*>(blk + rr * 64 + ((rc ^ ((rr >> 1) & 3)) << 4));
+            const int m = m_base + i * 16 + rr, n_in = n_base + 32 * (rc >> 1);   // 16 output columns <- one 32-row (gate, up) block
+            if (m < p.M && n_in < p.N) {
+                long orow = m;
+                if (p.row_map) orow = p.row_map[m];
+                if (orow >= 0) *reinterpret_cast<u32x4*>((bf16*)p.out + orow * p.ldo + n_out0 + 8 * rc) = v;
+            }
+        }
+        return;
+    }
+    if (p.out_kind == 0) {                                                // bf16 out: 16 rows x 64 columns per block (128-byte rows)
+        const int rc = lane & 7;
+        const int n = n_base + 8 * rc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            char* blk = st + (i & 1) * 2048;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[j][i];
+                const int nb = n_base + j * 16 + 4 * g;
+                if (p.bias && nb < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + nb);
+                if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+                const int chunk = 2 * j + (g >> 1);
+                *reinterpret_cast<bf16x4*>(blk + li * 128 + ((chunk ^ (li & 7)) << 4) + (g & 1) * 8) = o;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = (lane >> 3) + 8 * h;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(blk + rr * 128 + ((rc ^ (rr & 7)) << 4));
+                const int m = m_base + i * 16 + rr;
+                if (m >= p.M || n >= p.N) continue;
+                long orow = m;
+                if (p.row_map) {
+                    orow = p.row_map[m];
+                    if (orow < 0) continue;
+                }
+                if (p.res_kind == 2) {                                   // MLX bf16 add: both operands bf16, sum rounded once
+                    const long rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>((const bf16*)p.res + rrow * p.ldres + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
+                }
+                *reinterpret_cast<bf16x8*>((bf16*)p.out + orow * p.ldo + n) = v;
+            }
+        }
+        return;
+    }
+    // fp32 out (+ optional fp32 residual): 16 rows x 64 columns per block (256-byte rows), one block in flight
+    const int rc = lane & 15;
+    const int n = n_base + 4 * rc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[j][i];
+            const int nb = n_base + j * 16 + 4 * g;
+            if (p.bias && nb < p.N) v += *reinterpret_cast<const f32x4*>(p.bias + nb);
+            if (p.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            *reinterpret_cast<f32x4*>(st + li * 256 + (((4 * j + g) ^ li) << 4)) = v;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int rr = (lane >> 4) + 4 * h;
+            f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * 256 + ((rc ^ rr) << 4));
+            const int m = m_base + i * 16 + rr;
+            if (m >= p.M || n >= p.N) continue;
+            long orow = m;
+            if (p.row_map) {
+                orow = p.row_map[m];
+                if (orow < 0) continue;
+            }
+            if (p.res_kind == 1) {
+                const long rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+                v += *reinterpret_cast<const f32x4*>((const float*)p.res + rrow * p.ldres + n);
+            }
+            *reinterpret_cast<f32x4*>((float*)p.out + orow * p.ldo + n) = v;
+        }
+    }
+}
+
 template <int CONV, bool FAST = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_bf16_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * BM * BK * 2];   // A0 | W0 | A1 | W1, 16 KB each
@@ -158,19 +284,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int k = k0 + slot * 8;
         const bool kin = k < p.K;
         int tap_off = 0, kh = 0, kw = 0;
-        if (CONV) {
-            const int tap = k / p.Cin;
-            const int ci = k - tap * p.Cin;
+        bool cin_ok = true;
+        if (CONV) {                                          // chunk-major K: k-tile kt = (64-channel chunk, tap), see conv3x3s2
+            const int kt = k0 >> 6, chunk = kt / 9, tap = kt - 9 * chunk;
             kh = tap / 3;
             kw = tap - 3 * kh;
-            tap_off = ci;
+            tap_off = chunk * 64 + slot * 8;
+            cin_ok = tap_off < p.Cin;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (CONV) {
                 const int ih = a_ih0[q] + kh, iw = a_iw0[q] + kw;
-                if (a_ok[q] && kin && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
+                if (a_ok[q] && kin && cin_ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
                     v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + tap_off));
             } else {
                 if (a_ok[q] && kin) v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + k);
@@ -308,9 +435,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const int k = k0 + slot * 8;
         const bool kin = k < p.K;
         int ci = 0, kh = 0, kw = 0;
-        if (CONV) {
-            const int tap = k / p.Cin;
-            ci = k - tap * p.Cin;
+        bool cin_ok = true;
+        if (CONV) {                                          // chunk-major K (see conv3x3s2)
+            const int kt = k0 >> 6, chunk = kt / 9, tap = kt - 9 * chunk;
+            ci = chunk * 64 + slot * 8;
+            cin_ok = ci < p.Cin;
             kh = tap / 3;
             kw = tap - 3 * kh;
         }
@@ -319,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (CONV) {
                 const int ih = a_ih0[q] + kh, iw = a_iw0[q] + kw;
-                if (a_ok[q] && kin && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
+                if (a_ok[q] && kin && cin_ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
                     v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + ci));
             } else {
                 if (a_ok[q] && kin) v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + k);
@@ -397,6 +526,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 // issues the DMA.  A buffer is read one phase after the wait that retires it (+ the barrier), never in the same phase.
 // ---------------------------------------------------------------------------
 #define G8_SLOT 16384
+#define G8_LDS (8 * G8_SLOT + 8 * 4096)      // ring + per-wave epilogue staging = all 160 KiB of the CU
 #define G8_BAR()                                   \
     do {                                           \
         asm volatile("" ::: "memory");             \
@@ -413,8 +543,11 @@ struct G8Ctx {
     int wave_lds;                          // wave * 1024
     unsigned rdA, rdB;                     // this lane's fragment read offsets inside a half-tile (kk = 0; kk = 1 is ^ 64)
     int nk;
-    // implicit-GEMM conv (k3 s2 p1): offA holds the image's first pixel index instead; per staged row 2*oh | 2*ow << 16
+    // implicit-GEMM conv (k3 s2 p1): offA = byte offset of this lane's 16 bytes at tap (0,0), chunk 0, relative to Atile (the
+    // tile's first image, moved back by one input row and one pixel so that every offset is >= 0); ahw = 9-bit mask of the
+    // taps whose input pixel lies inside the image
     unsigned ahw[2][2];
+    const char* Atile;
     unsigned kslot[2];                     // 8 * (k slot this lane stages), per instruction
     int Hin, Win, Cin, K;
     // plain GEMM (persistent over tiles): offsets are rebuilt from the tile origin at every issue
@@ -441,32 +574,29 @@ __device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile, int tm0, int
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + 8192 * q), 16, 0, 0);
         }
-    } else if constexpr ((KIND & 1) == 0) {                                 // weights: rows of 9*Cin, zero beyond K
+    } else if constexpr ((KIND & 1) == 0) {                                 // weights: rows of K (chunk-major), zero beyond K
         const char* zero = reinterpret_cast<const char*>(g8_zero);
+        const bool k_ok = kt * 64 < c.K;                                    // scalar (odd tile counts are padded to even)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int k = kt * 64 + (int)c.kslot[q];
-            const char* src = k < c.K ? c.W + (c.offW[h][q] + (unsigned)kt * 128u) : zero;
+            const char* src = k_ok ? c.W + (c.offW[h][q] + (unsigned)kt * 128u) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + 8192 * q), 16, 0, 0);
         }
     } else {                                                                // activations: im2col address per lane
-        // a K tile (64) touches at most two taps (Cin >= 64): tap0 from the tile's first k (scalar), tap0 + 1 past kb
-        const int k0 = kt * 64;
-        const int tap0 = k0 / c.Cin, kb = (tap0 + 1) * c.Cin;
-        const int kh0 = tap0 / 3, kw0 = tap0 - 3 * kh0;
-        const int tap1 = tap0 + 1, kh1 = tap1 / 3, kw1 = tap1 - 3 * kh1;
+        // chunk-major K: K tile kt = (64-channel chunk kt / 9, tap kt % 9) -- the nine taps of a chunk are consecutive, so
+        // the input lines they share (2.1 taps per line on average) are re-read while still in L2.  Per lane and DMA only
+        // an add, a mask test and the zero-line select remain here (the phase's VALU issue slots are shared with the
+        // partner wave's MFMAs: 44 VALU per phase made this loop issue-bound, 2.15 us per K tile against 1.28 plain).
+        const int chunk = kt / 9, tap = kt - 9 * chunk;                     // scalar
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const unsigned soff = (unsigned)(((kh * c.Win + kw) * c.Cin + chunk * 64) * 2);
+        const int cmax = (kt * 64 < c.K) ? c.Cin - chunk * 64 : 0;          // channels of this chunk that exist (0: padding tile)
         const char* zero = reinterpret_cast<const char*>(g8_zero);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int k = k0 + (int)c.kslot[q];
-            const bool second = k >= kb;
-            const int ci = k - (second ? kb : kb - c.Cin);
-            const int ih = (int)(c.ahw[h][q] & 0xFFFFu) - 1 + (second ? kh1 : kh0);
-            const int iw = (int)(c.ahw[h][q] >> 16) - 1 + (second ? kw1 : kw0);
-            const bool in = k < c.K && (unsigned)ih < (unsigned)c.Hin && (unsigned)iw < (unsigned)c.Win;
-            const long off = ((long)(c.offA[h][q] + (unsigned)(ih * c.Win + iw)) * c.Cin + ci) * 2;
-            const char* src = in ? c.A + off : zero;
+            const bool in = ((c.ahw[h][q] >> tap) & 1u) != 0 && (int)c.kslot[q] < cmax;
+            const char* src = in ? c.Atile + (c.offA[h][q] + soff) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + 8192 * q), 16, 0, 0);
         }
@@ -532,7 +662,7 @@ __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0
 // stagger again after it.  The conv variant takes one tile per workgroup (its per-row im2col state is per tile).
 template <int CONV>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int total_tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem8[];          // the only LDS object: 8 ring slots x 16 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem8[];          // the only LDS object: 8 ring slots x 16 KiB + 8 x 4 KiB epilogue staging
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.N + G2_T - 1) / G2_T, tiles_m = (p.M + G2_T - 1) / G2_T;
@@ -577,10 +707,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
                 const int rowW = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
                 c.offW[h][q] = (unsigned)(((long)rowW * p.ldw + c.kslot[q]) * 2);
                 const int hw = p.Hout * p.Wout;
+                const int img0 = m0 / hw;                                   // first image of this tile (uniform)
                 const int img = rowA / hw, rem = rowA - img * hw;
                 const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
-                c.offA[h][q] = (unsigned)img * (unsigned)(p.Hin * p.Win);
-                c.ahw[h][q] = (unsigned)(2 * oh) | ((unsigned)(2 * ow) << 16);
+                c.Atile = reinterpret_cast<const char*>(p.A) + ((long)img0 * p.Hin * p.Win - (p.Win + 1)) * p.Cin * 2;
+                c.offA[h][q] = (unsigned)(((img - img0) * p.Hin * p.Win + 2 * oh * p.Win + 2 * ow) * p.Cin + (int)c.kslot[q]) * 2u;
+                unsigned mask = 0;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ih = 2 * oh - 1 + tap / 3, iw = 2 * ow - 1 + tap % 3;
+                    if ((unsigned)ih < (unsigned)p.Hin && (unsigned)iw < (unsigned)p.Win) mask |= 1u << tap;
+                }
+                c.ahw[h][q] = mask;
             }
         }
     c.rdA = (unsigned)((wr * 64 + li) * 128 + ((g ^ (li >> 1)) << 4));
@@ -620,7 +758,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
             g8_phase<7, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
         }
         if (wr == 0) G8_BAR();                                             // re-align the wave rows
-        gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
+        if (p.lds_epi) gemm_epilogue_lds(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
+        else gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
         v += gridDim.x;
         if (CONV || v >= total_tiles) break;                               // uniform
         m0 = m0n; n0 = n0n;
@@ -650,17 +789,24 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
     const unsigned rounds8 = (tiles256 + 255) / 256, rounds128 = (tiles + 255) / 256;
     const bool want8 = can8 && 2.6f * rounds8 < 1.0f * rounds128;
     const bool big = mode == 256 || (mode != 128 && mode != 8 && tiles256 >= 6 * 256);
-    const bool can8c = conv && p.Cin >= 64 && p.K >= 256 && (long)p.N * p.ldw < (1L << 31) && p.Hin < 32768 && p.Win < 32768 &&
-                       (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win < (1L << 32);
+    // a 256-row tile spans at most 256 / (Hout*Wout) + 2 images: their bytes must fit the 32-bit lane offsets
+    const bool can8c = conv && p.K >= 256 && (long)p.N * p.ldw < (1L << 31) &&
+                       (256L / (p.Hout * p.Wout) + 3) * p.Hin * p.Win * p.Cin * 2 < (1L << 31);
     const bool want8c = can8c && tiles256 >= 192;
     if ((mode == 8 && (can8 || can8c)) || (mode == 0 && (want8 || want8c))) {      // deep-pipelined 8-phase kernel
+        GemmParams p8 = p;
+        static const int epi_env = [] { const char* e = getenv("Q3ASR_GEMM_LDS_EPI"); return e ? atoi(e) : 1; }();
+        const long esz = p.out_kind == 1 ? 4 : 2;
+        p8.lds_epi = epi_env && p.N % 8 == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0 && (p.ldo * esz) % 16 == 0 &&
+                     (p.res_kind == 0 || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
+                     (!p.bias || ((uintptr_t)p.bias & 15) == 0);
         static bool attr8 = false;
         if (!attr8) {
-            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
-            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * G8_SLOT);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
             attr8 = true;
         }
-        if (conv) hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), 8 * G8_SLOT, s, p, (int)tiles256);
+        if (conv) hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), G8_LDS, s, p8, (int)tiles256);
         else {
             // persistent (one workgroup per CU walking the tile list) where tiles are short and the epilogue light:
             // it hides the dispatch and the pipeline fill of every tile after the first, but its epilogue stores must
@@ -669,7 +815,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
             static const int force = [] { const char* e = getenv("Q3ASR_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
             const bool persist = force >= 0 ? force != 0 : (p.K <= 2048 && p.act != 2);
             const unsigned grid = persist && tiles256 > 256u ? 256u : tiles256;
-            hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(grid), dim3(512), 8 * G8_SLOT, s, p, (int)tiles256);
+            hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles256);
         }
         return;
     }
@@ -725,16 +871,20 @@ extern "C" int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_
 }
 
 // Conv2d k3 s2 p1 over NHWC bf16 as implicit GEMM (encoder.py:155-168,274-275).
-// x [imgs][Hin][Win][Cin]; w [Cout][3][3][Cin] (tap order follows x's two spatial dims);
+// x [imgs][Hin][Win][Cin]; w in CHUNK-MAJOR K order [Cout][ceil(Cin/64)][9 taps][64] (tap = 3*kh + kw over x's two spatial
+// dims; channels beyond Cin are zero) = ops.conv_weight_chunked: the nine taps of a 64-channel chunk are consecutive K
+// tiles, so the input lines neighbouring taps share are re-read from L2 instead of from beyond it (r1 PMC: 3.4x the
+// input bytes fetched with tap-major K).  All three kernels walk K in this order: bit-identical results.
 // out row m = (img*Hout + oh)*Wout + ow, or row_map[m].
 extern "C" int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, int Cin, const void* w, int Cout,
                                     const float* bias, int act, void* out, int out_kind, int64_t ldo,
                                     const int32_t* row_map, void* stream) {
     GemmParams p{};
-    p.A = (const bf16*)x; p.lda = 0; p.W = (const bf16*)w; p.ldw = 9L * Cin;
+    const int kc = ((Cin + 63) / 64) * 9 * 64;                             // chunk-major K, channels padded to 64
+    p.A = (const bf16*)x; p.lda = 0; p.W = (const bf16*)w; p.ldw = kc;
     p.Hin = Hin; p.Win = Win; p.Cin = Cin;
     p.Hout = (Hin - 1) / 2 + 1; p.Wout = (Win - 1) / 2 + 1;
-    p.M = imgs * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin;
+    p.M = imgs * p.Hout * p.Wout; p.N = Cout; p.K = kc;
     p.bias = bias; p.act = act; p.out = out; p.out_kind = out_kind; p.ldo = ldo; p.row_map = row_map;
     Q3_REQUIRE(imgs > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cin % 8 == 0, "conv3x3s2: bad geometry (Cin=%d must be a multiple of 8)", Cin);
     Q3_REQUIRE((long)imgs * p.Hout * p.Wout < 2147483647L, "conv3x3s2: M overflows int32");

@@ -105,7 +105,7 @@ class AudioEncoder:
         w["c1_w"] = f32(W["conv2d1.weight"].to(dev)[..., 0].permute(0, 2, 1))                   # [C1][kt][kf]
         w["c1_b"] = f32(W["conv2d1.bias"])
         for i in (2, 3):
-            w[f"c{i}_w"] = bf(W[f"conv2d{i}.weight"].to(dev).permute(0, 2, 1, 3)).reshape(C1, 9 * C1)
+            w[f"c{i}_w"] = ops.conv_weight_chunked(bf(W[f"conv2d{i}.weight"].to(dev).permute(0, 2, 1, 3)))   # (O, kt, kf, I) -> chunk-major K
             w[f"c{i}_b"] = f32(W[f"conv2d{i}.bias"])
         fq = W["conv_out.weight"].shape[1] // C1
         # conv_out input index is ch*freq + f (encoder.py:278); our rows are [f][ch]

@@ -19,7 +19,19 @@ def gemm(A, W, M, N, K, out, *, lda=None, ldw=None, bias=None, act=0, res=None, 
          ldo if ldo is not None else (N // 2 if act == 2 else N), ptr(row_map), sp())
 
 
+def conv_weight_chunked(w):
+    """[Cout][3][3][Cin] (tap order = the activations' two spatial dims) -> chunk-major K [Cout][ceil(Cin/64) * 9 * 64]
+    with zero channels beyond Cin (csrc/gemm.hip, q3asr_conv3x3s2_bf16).  One-time re-tiling of static weights."""
+    import torch
+    Cout, Cin = w.shape[0], w.shape[-1]
+    nch = (Cin + 63) // 64
+    t = torch.zeros((Cout, 9, nch * 64), dtype=w.dtype, device=w.device)
+    t[:, :, :Cin] = w.reshape(Cout, 9, Cin)
+    return t.reshape(Cout, 9, nch, 64).permute(0, 2, 1, 3).reshape(Cout, nch * 576).contiguous()
+
+
 def conv3x3s2(x, imgs, Hin, Win, Cin, w, Cout, bias, act, out):
+    """w: conv_weight_chunked layout."""
     call("q3asr_conv3x3s2_bf16", ptr(x), imgs, Hin, Win, Cin, ptr(w), Cout, ptr(bias), act, ptr(out), 0, Cout, None, sp())
 
 

@@ -607,7 +607,8 @@ def test_run_sharded_over_rccl_world1(dev, small):
 
 def test_front_door_fails_fast_after_worker_death(dev, small, monkeypatch):
     """once the row worker has died, queued and later requests must fail instead of hanging."""
-    from qwen3_asr_mlx_amd import generate as gen
+    import importlib
+    gen = importlib.import_module("qwen3_asr_mlx_amd.generate")     # the package attribute `generate` is the function
     from qwen3_asr_mlx_amd.serve import ContinuousTranscriber
     cfg, state, model = small
     calls = {"n": 0}

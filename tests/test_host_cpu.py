@@ -313,11 +313,14 @@ def test_mlx_conv_layout_maps_to_time_major_taps_at_full_conv_shapes():
     C = 480
     w2, w3 = W["conv2d2.weight"].float(), W["conv2d3.weight"].float()
     assert w2.shape == (C, 3, 3, C) and W["conv2d1.weight"].shape == (C, 3, 3, 1) and W["conv_out.weight"].shape == (1024, C * 16)
+    assert enc.w["c2_w"].shape == (C, 8 * 9 * 64)                         # 480 channels = 7.5 chunks of 64: padded with zeros
+    assert float(enc.w["c2_w"][:, 7 * 576:].reshape(C, 9, 64)[:, :, 32:].abs().max()) == 0.0
     g = torch.Generator().manual_seed(0)
     for _ in range(200):
         o, kf, kt, i = (int(torch.randint(0, n, (1,), generator=g)) for n in (C, 3, 3, C))
-        assert float(enc.w["c2_w"][o, (kt * 3 + kf) * C + i]) == float(w2[o, kf, kt, i])
-        assert float(enc.w["c3_w"][o, (kt * 3 + kf) * C + i]) == float(w3[o, kf, kt, i])
+        kc = ((i // 64) * 9 + kt * 3 + kf) * 64 + i % 64                  # chunk-major K: (64-channel chunk, tap, channel)
+        assert float(enc.w["c2_w"][o, kc]) == float(w2[o, kf, kt, i])
+        assert float(enc.w["c3_w"][o, kc]) == float(w3[o, kf, kt, i])
         assert float(enc.w["c1_w"][o, kt, kf]) == float(W["conv2d1.weight"][o, kf, kt, 0])
         d, f = int(torch.randint(0, 1024, (1,), generator=g)), int(torch.randint(0, 16, (1,), generator=g))
         assert float(enc.w["co_w"][d, f * C + i]) == float(W["conv_out.weight"][d, i * 16 + f])

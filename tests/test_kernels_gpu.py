@@ -200,6 +200,13 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     W = rnd((N, K), dev, 41, 1.0 / math.sqrt(K))
     bias = rnd((N,), dev, 42, 0.5, torch.float32)
     hb = rnd((M, N), dev, 43)
+    h0 = rnd((M, N), dev, 44, 1.0, torch.float32)
+    pe = rnd((13, N), dev, 45, 1.0, torch.float32)
+    rm = torch.tensor([i if i % 5 else -1 for i in range(M)], dtype=torch.int32)
+    keep = rm >= 0
+    n_keep = int(keep.sum())
+    rm[keep] = torch.arange(n_keep, dtype=torch.int32)
+    rm = rm.to(dev)
     outs = {}
     try:
         for mode in (128, 256, 8):
@@ -212,7 +219,11 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
             ops.gemm(A, W, M, N, K, orr, res=hb, res_kind=2, ldres=N)
             osw = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev)
             ops.gemm(A, W, M, N, K, osw, act=2)
-            outs[mode] = (o32, og, orr, osw)
+            h32 = h0.clone()                                                  # bias + fp32 residual in place (encoder out / fc2)
+            ops.gemm(A, W, M, N, K, h32, bias=bias, res=h32, res_kind=1, ldres=N, out_fp32=True)
+            opk = torch.zeros((n_keep, N), dtype=torch.float32, device=dev)   # modulo-row residual + row map (conv_out + PE + pad strip)
+            ops.gemm(A, W, M, N, K, opk, res=pe, res_kind=1, ldres=N, res_mod=13, out_fp32=True, row_map=rm)
+            outs[mode] = (o32, og, orr, osw, h32, opk)
     finally:
         _lib.call("q3asr_gemm_force_kernel", 0)
     torch.testing.assert_close(outs[8][0].cpu(), _gemm_ref(A, W), atol=2e-3, rtol=1e-3)
@@ -282,7 +293,7 @@ def test_conv3x3s2_implicit_gemm(dev, imgs, H, W_, C):
     b = rnd((C,), dev, 52, 0.3, torch.float32)
     Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
     out = torch.empty((imgs, Ho, Wo, C), dtype=torch.bfloat16, device=dev)
-    ops.conv3x3s2(x, imgs, H, W_, C, w.reshape(C, 9 * C), C, b, 1, out)
+    ops.conv3x3s2(x, imgs, H, W_, C, ops.conv_weight_chunked(w), C, b, 1, out)
     ref = F.gelu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), b.cpu(), stride=2, padding=1))
     torch.testing.assert_close(out.float().cpu(), bfr(ref.permute(0, 2, 3, 1)), atol=2e-2, rtol=8e-3)
 
@@ -301,7 +312,7 @@ def test_conv3x3s2_kernels_agree_bitwise(dev, imgs, H, W_, C, Co):
         for mode in (128, 256, 8):
             _lib.call("q3asr_gemm_force_kernel", mode)
             o = torch.empty((imgs, Ho, Wo, Co), dtype=torch.bfloat16, device=dev)
-            ops.conv3x3s2(x, imgs, H, W_, C, w.reshape(Co, 9 * C), Co, b, 1, o)
+            ops.conv3x3s2(x, imgs, H, W_, C, ops.conv_weight_chunked(w), Co, b, 1, o)
             outs[mode] = o
     finally:
         _lib.call("q3asr_gemm_force_kernel", 0)
@@ -668,7 +679,7 @@ def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
              hd ** -0.5, ops.sp())
     MT = ops.mt_of(B)
     nbytes = _lib.load().q3asr_attn_decode_fused_workspace(B, nkv, Lmax)
-    assert nbytes == 4 * (B * nkv * ((Lmax + 1023) // 1024) * 260 + B * nkv)
+    assert nbytes == 4 * (B * nkv * ((Lmax + 1023) // 1024) * 260 + B * nkv)   # ADF_CHUNK = 1024
     wsp = torch.zeros((nbytes // 4,), dtype=torch.float32, device=dev)
     outs = []
     for rep in range(3):                                       # same workspace, back to back

@@ -217,7 +217,9 @@ def test_config5_full_size_longform_fp8_sampling(dev):
     model.py:382-447), temperature 0.7 / top-p 0.9: 40 segments, each with the reference budget max(256, 50/s), decoded
     as one batch; same seed -> same transcript."""
     import qwen3_asr_mlx_amd as q
-    from qwen3_asr_mlx_amd import generate as gen, synth
+    import importlib
+    from qwen3_asr_mlx_amd import synth
+    gen = importlib.import_module("qwen3_asr_mlx_amd.generate")     # the package attribute `generate` is the function
     from qwen3_asr_mlx_amd.config import ModelConfig
     from qwen3_asr_mlx_amd.model import _find_split_points
     cfg = ModelConfig()

@@ -9,7 +9,7 @@ from qwen3_asr_mlx_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")
 for (imgs, H, W, C, name) in [(960, 64, 50, 480, "conv2"), (960, 32, 25, 480, "conv3")]:
     x = torch.randn(imgs, H, W, C, device=dev).to(torch.bfloat16)
-    w = (torch.randn(C, 9 * C, device=dev) * 0.02).to(torch.bfloat16)
+    w = ops.conv_weight_chunked((torch.randn(C, 3, 3, C, device=dev) * 0.02).to(torch.bfloat16))
     b = torch.zeros(C, device=dev)
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     out = torch.empty((imgs, Ho, Wo, C), dtype=torch.bfloat16, device=dev)

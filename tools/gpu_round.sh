@@ -26,6 +26,7 @@ for step in "$@"; do
     case $step in
     tests)        run 900 $O/${TAG}_tests.log python3 -m pytest $R/tests -m gpu -q -x --deselect $R/tests/test_parity_gpu.py ; tail -5 $O/${TAG}_tests.log ;;
     tests_parity) run 900 $O/${TAG}_parity.log python3 -m pytest $R/tests/test_parity_gpu.py -m gpu -q -s ; tail -15 $O/${TAG}_parity.log ;;
+    tests_k)      run 600 $O/${TAG}_tests_k.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x ; tail -5 $O/${TAG}_tests_k.log ;;
     tests_all)    run 1100 $O/${TAG}_tests_all.log python3 -m pytest $R/tests -m gpu -q -x ; tail -5 $O/${TAG}_tests_all.log ;;
     bench)        run 600 $O/${TAG}_bench.err python3 $R/bench.py --steps 20 --warmup 3 ; grep '^{' $O/${TAG}_bench.err > $O/${TAG}_bench.json; grep -v '^{' $O/${TAG}_bench.err | tail -25 ;;
     benchq)       run 400 $O/${TAG}_benchq.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchq.err > $O/${TAG}_benchq.json; grep -v '^{' $O/${TAG}_benchq.err | tail -12 ;;
@@ -39,6 +40,14 @@ for step in "$@"; do
     probe_batch1) prof probe_batch1 batch1 --pmc FETCH_SIZE --kernel-trace ;;
     probe_graph)  prof probe_graph graph --pmc FETCH_SIZE --kernel-trace ;;
     probe_graph4) prof probe_graph4 graph4 --pmc FETCH_SIZE --kernel-trace ;;
+    probe_regraph) prof probe_regraph regraph --pmc FETCH_SIZE --kernel-trace ;;
+    bench_pmc)    rm -rf $O/${TAG}_bench_pmc; run 600 $O/${TAG}_bench_pmc.log rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_bench_pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipeline --no-extra-configs
+                  find $O/${TAG}_bench_pmc -name '*.csv' -size +1M -delete; tail -12 $O/${TAG}_bench_pmc.log ;;
+    gemmk)        run 300 $O/${TAG}_gemmk.log python3 $R/tools/bench_gemm_k.py 5 ; cat $O/${TAG}_gemmk.log
+                  Q3ASR_GEMM_PERSIST=0 run 300 $O/${TAG}_gemmk_np.log python3 $R/tools/bench_gemm_k.py 5 ; cat $O/${TAG}_gemmk_np.log ;;
+    bench_pmc16)  rm -rf $O/${TAG}_bench_pmc16; run 600 $O/${TAG}_bench_pmc16.log rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_bench_pmc16 -- python3 $R/bench.py --steps 1 --warmup 1 --ndec 16 --no-cpu-baseline --no-pipeline --no-extra-configs
+                  find $O/${TAG}_bench_pmc16 -name '*.csv' -size +1M -delete; tail -12 $O/${TAG}_bench_pmc16.log ;;
+    stage)        run 300 $O/${TAG}_stage.log python3 $R/tools/stage_profile.py 32 30 $O/${TAG}_stage.json ; cat $O/${TAG}_stage.log ;;
     *) echo "unknown step $step" ;;
     esac
 done

@@ -9,6 +9,8 @@ threads, no side streams, no graph capture unless asked for.  Runs, eagerly, on 
   batch1   4 eager decode steps at batch 1 (the fused residual+norm GEMM path, 144 KiB of dynamic LDS)
   graph    capture the batch-32 decode step into a hipGraph and replay it 4 times
   graph4   the same with the 4-step graph
+  regraph  capture, replay, DESTROY the graph, capture again, replay (what bench.py's stage leg does to a workspace that
+           already holds a graph)
 
 Usage: python3 tools/pmc_probe.py decode,encoder [--batch 32] [--seconds 30]
 Writes gpurun_out/pmc_probe_meta.json: sha-256 (first 16 hex) of the library that ran, and what ran."""
@@ -47,7 +49,7 @@ def say(msg):
 sampling = {"temperature": 0.0, "top_p": 1.0, "top_k": 0, "repetition_penalty": 1.2, "repetition_context_size": 100, "seed": 0}
 n = int(secs * 16000)
 feats = counts = None
-if what & {"encoder", "prefill", "step", "graph", "graph4", "batch1"}:
+if what & {"encoder", "prefill", "step", "graph", "graph4", "batch1", "regraph"}:
     audio, lens_dev, lens = q.audio.pack_audio([signal("speechlike", n, seed=1234 + i) for i in range(B)], dev)
     mel, n_frames = q.audio.get_frontend(dev)(audio, lens_dev, lens)
     feats, counts = enc.forward_batch(mel, n_frames)
@@ -76,7 +78,7 @@ if "decode" in what:
         dec.gemm_only_step(ws)
     torch.cuda.synchronize()
     say("decode GEMMs done")
-if what & {"prefill", "step", "graph", "graph4"}:
+if what & {"prefill", "step", "graph", "graph4", "regraph"}:
     ws, cache = prefilled(B)
     say("prefill done")
     if "step" in what:
@@ -96,6 +98,18 @@ if what & {"prefill", "step", "graph", "graph4"}:
                 side.synchronize()
                 _lib.call("q3asr_graph_destroy", g)
             say(f"{name}: captured and replayed")
+    if "regraph" in what:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dec.decode_step(ws, cache, sampling)
+            for rep in range(3):
+                g = dec._capture(ws, cache, sampling, 1 if rep != 1 else dec.MULTI_STEPS)
+                for _ in range(3):
+                    _lib.call("q3asr_graph_launch", g, torch.cuda.current_stream().cuda_stream)
+                _lib.call("q3asr_graph_destroy", g)               # destroyed while its launches may still be in flight
+            side.synchronize()
+        say("regraph: capture / replay / destroy x3 done")
 if "batch1" in what:
     ws1, cache1 = prefilled(1)
     for _ in range(4):
