@@ -39,6 +39,10 @@ int q3asr_log_mel(const float* audio, int64_t audio_stride, const int32_t* lens_
 int q3asr_conv1_gelu(const float* mel, int Fmax, const int32_t* chunk_b, const int32_t* chunk_f0, int n_chunks,
                      const float* w9, const float* bias, void* out, int C1, void* stream);
 
+/* the same with float32 output (reference-semantics encoder mode: fp32 activations, see "parity mode" below) */
+int q3asr_conv1_gelu_f32(const float* mel, int Fmax, const int32_t* chunk_b, const int32_t* chunk_f0, int n_chunks,
+                         const float* w9, const float* bias, float* out, int C1, void* stream);
+
 /* ---- encoder.py:274-275  conv2d2 / conv2d3 (+GELU) as implicit GEMM --------------------------
  * x bf16 [imgs][Hin][Win][Cin]; w bf16 in chunk-major K order [Cout][ceil(Cin/64)][9 taps][64] (tap = 3*kh + kw over
  * x's two spatial dims, zero channels beyond Cin: the nine taps of a 64-channel chunk are consecutive K tiles);
@@ -65,6 +69,18 @@ int q3asr_gemm_force_kernel(int mode);
 /* ---- nn.LayerNorm (encoder.py:112,117,319): x fp32 [M][D] -> y bf16 [M][D] ------------------ */
 int q3asr_layernorm_f32_bf16(const float* x, const float* w, const float* b, void* y, int M, int D, float eps,
                              void* stream);
+
+/* ---- parity mode of the encoder (reference semantics: float32 activations through encoder.py:272-323, nothing is cast
+ * after audio.py:278).  An fp32 activation is split into three bf16 pieces hi + mid + lo laid side by side along K,
+ * [M][3K] = [hi | mid | lo]; q3asr_gemm_bf16 / q3asr_conv3x3s2_bf16 on it against [W | W | W] give an fp32-accurate
+ * x . W^T (exact bf16 products, fp32 accumulation).  csrc/parity.hip. */
+int q3asr_split3_f32(const float* x, int64_t ldx, void* y, int64_t M, int K, void* stream);
+/* LayerNorm with the fp32 result split: y bf16 [M][3D] */
+int q3asr_layernorm_f32_split3(const float* x, const float* w, const float* b, void* y, int M, int D, float eps, void* stream);
+/* mx.fast.scaled_dot_product_attention at encoder.py:82-84 on fp32 q/k/v: qkv fp32 [N][ld >= 3*d_model] (q | k | v),
+ * windows (seg_start, seg_len) of at most 128 tokens, head_dim 64; out fp32 [N][ldo]. */
+int q3asr_attn_fwd_f32(const float* qkv, int64_t ld, int d_model, const int32_t* seg_start, const int32_t* seg_len, int n_segs,
+                       int max_len, int n_heads, float scale, float* out, int64_t ldo, void* stream);
 
 /* ---- nn.RMSNorm (decoder.py:189,194,251): bf16 -> bf16; row_idx optional source-row gather -- */
 int q3asr_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const int32_t* row_idx,

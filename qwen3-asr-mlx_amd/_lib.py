@@ -20,6 +20,10 @@ _SIGS = {
     "q3asr_last_error": [],
     "q3asr_log_mel": [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "q3asr_conv1_gelu": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "q3asr_conv1_gelu_f32": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "q3asr_split3_f32": [_vp, _i64, _vp, _i64, _i, _vp],
+    "q3asr_layernorm_f32_split3": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "q3asr_attn_fwd_f32": [_vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i64, _vp],
     "q3asr_conv3x3s2_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _vp],
     "q3asr_gemm_bf16": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _i, _i64, _vp, _vp],
     "q3asr_layernorm_f32_bf16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],

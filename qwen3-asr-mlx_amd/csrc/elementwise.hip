@@ -15,10 +15,11 @@
 #define C1_TIN 100
 #define C1_FIN 128
 
+template <bool F32OUT>      // F32OUT: reference-semantics mode (csrc/parity.hip) keeps the activation in float32
 __global__ __launch_bounds__(256) void conv1_gelu_kernel(const float* __restrict__ mel, int Fmax,
                                                          const int* __restrict__ chunk_b, const int* __restrict__ chunk_f0,
                                                          const float* __restrict__ w9 /*[C1][kt][kf]*/,
-                                                         const float* __restrict__ bias, bf16* __restrict__ out, int C1) {
+                                                         const float* __restrict__ bias, void* __restrict__ out_, int C1) {
     // One workgroup per (chunk, output time step): 64 output frequencies x C1 channels.  A thread owns one
     // channel octet for the whole row: its 72 weights and 8 biases live in registers, the 3 input rows in
     // LDS are read as broadcasts (all lanes of a wave work on the same frequency at a time).
@@ -49,7 +50,9 @@ __global__ __launch_bounds__(256) void conv1_gelu_kernel(const float* __restrict
     }
     __syncthreads();
     if (fg >= groups) return;
-    bf16* obase = out + ((long)(ci * TOUT + ot) * FOUT) * C1 + oc * 8;
+    const long obase_i = ((long)(ci * TOUT + ot) * FOUT) * C1 + oc * 8;
+    bf16* obase = (bf16*)out_ + obase_i;
+    float* obase32 = (float*)out_ + obase_i;
     for (int of = fg; of < FOUT; of += groups) {
         float x[9];
 #pragma unroll
@@ -57,14 +60,21 @@ __global__ __launch_bounds__(256) void conv1_gelu_kernel(const float* __restrict
 #pragma unroll
             for (int kf = 0; kf < 3; ++kf) x[kt * 3 + kf] = in_s[kt * 130 + 2 * of + kf];   // f = 2*of-1+kf -> index +1
         bf16x8 o;
+        float o32[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float a = bb[e];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) a = fmaf(w[e][tap], x[tap], a);
-            o[e] = f2bf(gelu_erf(a));
+            o32[e] = gelu_erf(a);
+            o[e] = f2bf(o32[e]);
         }
-        *reinterpret_cast<bf16x8*>(obase + (long)of * C1) = o;
+        if constexpr (F32OUT) {
+            *reinterpret_cast<f32x4*>(obase32 + (long)of * C1) = f32x4{o32[0], o32[1], o32[2], o32[3]};
+            *reinterpret_cast<f32x4*>(obase32 + (long)of * C1 + 4) = f32x4{o32[4], o32[5], o32[6], o32[7]};
+        } else {
+            *reinterpret_cast<bf16x8*>(obase + (long)of * C1) = o;
+        }
     }
 }
 
@@ -72,9 +82,19 @@ extern "C" int q3asr_conv1_gelu(const float* mel, int Fmax, const int32_t* chunk
                                 const float* w9, const float* bias, void* out, int C1, void* stream) {
     Q3_REQUIRE(mel && chunk_b && chunk_f0 && w9 && bias && out, "conv1_gelu: null pointer");
     Q3_REQUIRE(n_chunks > 0 && Fmax > 0 && C1 > 0 && C1 % 8 == 0 && C1 <= 2048, "conv1_gelu: bad sizes (n_chunks=%d C1=%d, C1 <= 2048)", n_chunks, C1);
-    hipLaunchKernelGGL(conv1_gelu_kernel, dim3(50, n_chunks), dim3(256), 0, (hipStream_t)stream, mel, Fmax, chunk_b,
-                       chunk_f0, w9, bias, (bf16*)out, C1);
+    hipLaunchKernelGGL(conv1_gelu_kernel<false>, dim3(50, n_chunks), dim3(256), 0, (hipStream_t)stream, mel, Fmax, chunk_b,
+                       chunk_f0, w9, bias, out, C1);
     return q3_check_launch("conv1_gelu");
+}
+
+// the same with float32 output [n_chunks][50][64][C1] (reference-semantics mode)
+extern "C" int q3asr_conv1_gelu_f32(const float* mel, int Fmax, const int32_t* chunk_b, const int32_t* chunk_f0, int n_chunks,
+                                    const float* w9, const float* bias, float* out, int C1, void* stream) {
+    Q3_REQUIRE(mel && chunk_b && chunk_f0 && w9 && bias && out, "conv1_gelu_f32: null pointer");
+    Q3_REQUIRE(n_chunks > 0 && Fmax > 0 && C1 > 0 && C1 % 8 == 0 && C1 <= 2048, "conv1_gelu_f32: bad sizes (n_chunks=%d C1=%d, C1 <= 2048)", n_chunks, C1);
+    hipLaunchKernelGGL(conv1_gelu_kernel<true>, dim3(50, n_chunks), dim3(256), 0, (hipStream_t)stream, mel, Fmax, chunk_b,
+                       chunk_f0, w9, bias, (void*)out, C1);
+    return q3_check_launch("conv1_gelu_f32");
 }
 
 // ---------------------------------------------------------------------------

@@ -776,12 +776,12 @@ extern "C" int q3asr_gemm_force_kernel(int mode) {
     return 0;
 }
 
-static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
+static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force_mode = 0) {
     const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
     const bool fast = !conv && p.K % BK == 0 && (long)p.M * p.lda < (1L << 31) && (long)p.N * p.ldw < (1L << 31);
     const unsigned tiles256 = (unsigned)((p.M + G2_T - 1) / G2_T) * (unsigned)((p.N + G2_T - 1) / G2_T);
     if (g_gemm_mode < 0) { const char* e = getenv("Q3ASR_GEMM"); g_gemm_mode = e ? atoi(e) : 0; }
-    const int mode = g_gemm_mode;                            // 0 auto; 128 / 256 / 8 pin a kernel (A/B runs, tests)
+    const int mode = force_mode ? force_mode : g_gemm_mode;  // 0 auto; 128 / 256 / 8 pin a kernel (A/B runs, tests)
     // Kernel choice (measured on the prefill / encoder shapes, tools/bench_gemm.py): the 8-phase kernel wins wherever its
     // preconditions hold and the grid fills the chip: one 256^2 tile costs ~2.6 128^2 tiles, one workgroup per CU against
     // two (fc1 with its erf-GELU epilogue: 156 us against 181 us).
@@ -794,6 +794,9 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s) {
                        (256L / (p.Hout * p.Wout) + 3) * p.Hin * p.Win * p.Cin * 2 < (1L << 31);
     const bool want8c = can8c && tiles256 >= 192;
     if ((mode == 8 && (can8 || can8c)) || (mode == 0 && (want8 || want8c))) {      // deep-pipelined 8-phase kernel
+        // Tried (round 2, tools/ab_gemm_split.py): giving the rows of a mostly empty last round (784 tiles = 3.06 rounds) to the
+        // 128^2 kernel as a second launch -- fc1 142.5 -> 139.4 us, encoder qkv 88.7 -> 95.3 us, prefill qkv 200.6 -> 198.7 us: a
+        // K = 1024 tile of the 128^2 kernel plus the extra launch costs what the idle CUs of the last round cost.  Not kept.
         GemmParams p8 = p;
         static const int epi_env = [] { const char* e = getenv("Q3ASR_GEMM_LDS_EPI"); return e ? atoi(e) : 1; }();
         const long esz = p.out_kind == 1 ? 4 : 2;

@@ -42,8 +42,13 @@ class AudioEncoder:
         self.tokens_per_chunk = self._conv_output_length(self.chunk_size)
         self.window_tokens = self.tokens_per_chunk * (config.n_window_infer // self.chunk_size)
         self.w = None
+        self.w3 = None               # parity mode: [W | W | W] copies of every GEMM / conv weight, built on first use
         self.device = None
         self._plans: dict = {}
+        # "bf16": MFMA operands rounded to bf16 (fast path).  "fp32": the reference's semantics -- float32 activations end to
+        # end (audio.py:278, encoder.py:272-323 never cast), each GEMM fp32-accurate through the three-way bf16 split of
+        # csrc/parity.hip at three times the MFMA work.  For parity measurements, not throughput.
+        self.precision = "bf16"
 
     # ------------------------------------------------------------------ helpers (reference encoder.py:197-229)
     @staticmethod
@@ -104,8 +109,10 @@ class AudioEncoder:
         # conv weights: (O, kH=freq, kW=time, I) -> tap order (time, freq) for the time-major activations
         w["c1_w"] = f32(W["conv2d1.weight"].to(dev)[..., 0].permute(0, 2, 1))                   # [C1][kt][kf]
         w["c1_b"] = f32(W["conv2d1.bias"])
+        self._conv_w = {}
         for i in (2, 3):
-            w[f"c{i}_w"] = ops.conv_weight_chunked(bf(W[f"conv2d{i}.weight"].to(dev).permute(0, 2, 1, 3)))   # (O, kt, kf, I) -> chunk-major K
+            self._conv_w[i] = bf(W[f"conv2d{i}.weight"].to(dev).permute(0, 2, 1, 3))                       # (O, kt, kf, I)
+            w[f"c{i}_w"] = ops.conv_weight_chunked(self._conv_w[i])                                         # chunk-major K
             w[f"c{i}_b"] = f32(W[f"conv2d{i}.bias"])
         fq = W["conv_out.weight"].shape[1] // C1
         # conv_out input index is ch*freq + f (encoder.py:278); our rows are [f][ch]
@@ -128,7 +135,7 @@ class AudioEncoder:
         w["lnp_w"], w["lnp_b"] = f32(W["ln_post.weight"]), f32(W["ln_post.bias"])
         w["p1_w"], w["p1_b"] = bf(W["proj1.weight"]), f32(W["proj1.bias"])
         w["p2_w"], w["p2_b"] = bf(W["proj2.weight"]), f32(W["proj2.bias"])
-        self.w, self.device = w, dev
+        self.w, self.device, self.w3 = w, dev, None
 
     # ------------------------------------------------------------------ batch plan (host ints -> device index arrays)
     def _plan(self, n_frames: tuple):
@@ -178,6 +185,10 @@ class AudioEncoder:
         import torch
         if self.w is None:
             raise TypeError("AudioEncoder has no weights loaded")
+        if self.precision == "fp32":
+            return self._forward_batch_fp32(mel, n_frames)
+        if self.precision != "bf16":
+            raise ValueError(f"AudioEncoder.precision must be 'bf16' or 'fp32', got {self.precision!r}")
         cfg, w, dev = self.config, self.w, self.device
         pl = self._plan(tuple(int(n) for n in n_frames))
         Ct, N, d, C1 = pl["n_chunks"], pl["n_tokens"], cfg.d_model, cfg.downsample_hidden_size
@@ -215,6 +226,83 @@ class AudioEncoder:
         ops.gemm(xn, w["p1_w"], N, d, d, att, bias=w["p1_b"], act=1)
         out = torch.empty((N, cfg.output_dim), dtype=torch.float32, device=dev)
         ops.gemm(att, w["p2_w"], N, cfg.output_dim, d, out, bias=w["p2_b"], out_fp32=True)
+        return out, pl["tok_counts"]
+
+    # ------------------------------------------------------------------ reference-semantics forward (fp32 activations)
+    def _tripled(self) -> dict:
+        """[W | W | W] along K for every GEMM weight (and the convs' channel axis): the partner of a split activation."""
+        if self.w3 is None:
+            import torch
+            w, C1 = self.w, self.config.downsample_hidden_size
+            t3 = lambda m: torch.cat([m, m, m], dim=1).contiguous()              # noqa: E731
+            w3 = {"layers": []}
+            for i in (2, 3):
+                k4 = self._conv_w[i]                                               # (O, kt, kf, I) bf16
+                w3[f"c{i}_w"] = ops.conv_weight_chunked(torch.cat([k4, k4, k4], dim=-1))
+            fq = w["co_w"].shape[1] // C1
+            co = w["co_w"].reshape(-1, fq, C1)
+            w3["co_w"] = torch.cat([co, co, co], dim=2).reshape(co.shape[0], fq * 3 * C1).contiguous()
+            for L in w["layers"]:
+                w3["layers"].append({k: t3(L[k]) for k in ("wqkv", "wo", "w1", "w2")})
+            w3["p1_w"], w3["p2_w"] = t3(w["p1_w"]), t3(w["p2_w"])
+            self.w3 = w3
+        return self.w3
+
+    def _forward_batch_fp32(self, mel, n_frames: Sequence[int]):
+        """forward_batch with float32 activations end to end (the reference's arithmetic, encoder.py:249-323): every GEMM
+        operand is the three-way bf16 split of an fp32 tensor, attention / LayerNorm / GELU / residuals are fp32."""
+        import torch
+        cfg, w, w3, dev = self.config, self.w, self._tripled(), self.device
+        pl = self._plan(tuple(int(n) for n in n_frames))
+        Ct, N, d, C1 = pl["n_chunks"], pl["n_tokens"], cfg.d_model, cfg.downsample_hidden_size
+        nh, ffn = cfg.encoder_attention_heads, cfg.encoder_ffn_dim
+        f32, bf16 = torch.float32, torch.bfloat16
+        buf = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)         # noqa: E731
+
+        def split(x, rows, cols):
+            y = buf((rows, 3 * cols), bf16)
+            ops.split3(x, rows, cols, y)
+            return y
+        a1 = buf((Ct, 50, 64, C1), f32)
+        ops.call("q3asr_conv1_gelu_f32", ops.ptr(mel), mel.shape[2], ops.ptr(pl["chunk_b"]), ops.ptr(pl["chunk_f0"]), Ct,
+                 ops.ptr(w["c1_w"]), ops.ptr(w["c1_b"]), ops.ptr(a1), C1, ops.sp())
+        s1 = split(a1, Ct * 50 * 64, C1)
+        del a1
+        a2 = buf((Ct, 25, 32, C1), f32)
+        ops.conv3x3s2(s1, Ct, 50, 64, 3 * C1, w3["c2_w"], C1, w["c2_b"], 1, a2, out_fp32=True)
+        del s1
+        s2 = split(a2, Ct * 25 * 32, C1)
+        del a2
+        a3 = buf((Ct, 13, 16, C1), f32)
+        ops.conv3x3s2(s2, Ct, 25, 32, 3 * C1, w3["c3_w"], C1, w["c3_b"], 1, a3, out_fp32=True)
+        del s2
+        s3 = split(a3, Ct * 13 * 16, C1)                                         # token row = 16 x [hi | mid | lo] of 480 channels
+        del a3
+        hidden = buf((N, d), f32)
+        ops.gemm(s3, w3["co_w"], Ct * self.tokens_per_chunk, d, 16 * 3 * C1, hidden, res=w["pe"], res_kind=1, ldres=d,
+                 res_mod=self.tokens_per_chunk, out_fp32=True, row_map=pl["row_map"])
+        del s3
+        xn3 = buf((N, 3 * d), bf16)
+        qkv = buf((N, 3 * d), f32)
+        att = buf((N, d), f32)
+        ff = buf((N, ffn), f32)
+        scale = 64 ** -0.5
+
+        def ln(wgt, bias):
+            ops.call("q3asr_layernorm_f32_split3", ops.ptr(hidden), ops.ptr(wgt), ops.ptr(bias), ops.ptr(xn3), N, d, 1e-5, ops.sp())
+        for L, L3 in zip(w["layers"], w3["layers"]):
+            ln(L["ln1_w"], L["ln1_b"])
+            ops.gemm(xn3, L3["wqkv"], N, 3 * d, 3 * d, qkv, bias=L["bqkv"], out_fp32=True)
+            ops.call("q3asr_attn_fwd_f32", ops.ptr(qkv), 3 * d, d, ops.ptr(pl["seg_start"]), ops.ptr(pl["seg_len"]), pl["n_segs"],
+                     pl["max_seg"], nh, scale, ops.ptr(att), d, ops.sp())
+            ops.gemm(split(att, N, d), L3["wo"], N, d, 3 * d, hidden, bias=L["bo"], res=hidden, res_kind=1, ldres=d, out_fp32=True)
+            ln(L["ln2_w"], L["ln2_b"])
+            ops.gemm(xn3, L3["w1"], N, ffn, 3 * d, ff, bias=L["b1"], act=1, out_fp32=True)
+            ops.gemm(split(ff, N, ffn), L3["w2"], N, d, 3 * ffn, hidden, bias=L["b2"], res=hidden, res_kind=1, ldres=d, out_fp32=True)
+        ln(w["lnp_w"], w["lnp_b"])
+        ops.gemm(xn3, w3["p1_w"], N, d, 3 * d, att, bias=w["p1_b"], act=1, out_fp32=True)
+        out = buf((N, cfg.output_dim), f32)
+        ops.gemm(split(att, N, d), w3["p2_w"], N, cfg.output_dim, 3 * d, out, bias=w["p2_b"], out_fp32=True)
         return out, pl["tok_counts"]
 
     def __call__(self, mel):

@@ -30,9 +30,14 @@ def conv_weight_chunked(w):
     return t.reshape(Cout, 9, nch, 64).permute(0, 2, 1, 3).reshape(Cout, nch * 576).contiguous()
 
 
-def conv3x3s2(x, imgs, Hin, Win, Cin, w, Cout, bias, act, out):
+def conv3x3s2(x, imgs, Hin, Win, Cin, w, Cout, bias, act, out, out_fp32=False):
     """w: conv_weight_chunked layout."""
-    call("q3asr_conv3x3s2_bf16", ptr(x), imgs, Hin, Win, Cin, ptr(w), Cout, ptr(bias), act, ptr(out), 0, Cout, None, sp())
+    call("q3asr_conv3x3s2_bf16", ptr(x), imgs, Hin, Win, Cin, ptr(w), Cout, ptr(bias), act, ptr(out), 1 if out_fp32 else 0, Cout, None, sp())
+
+
+def split3(x, M, K, y, ldx=None):
+    """fp32 [M][K] -> bf16 [M][3K] = [hi | mid | lo] (csrc/parity.hip)."""
+    call("q3asr_split3_f32", ptr(x), ldx or K, ptr(y), M, K, sp())
 
 
 def layernorm(x, w, b, y, M, D, eps):

@@ -211,6 +211,67 @@ def test_full_size_margin_aware_tokens_512(dev, full_wide):
     assert g["exact_rate"] >= 0.8
 
 
+# ----------------------------------------------------------------------------- reference-semantics encoder mode (fp32 activations)
+@pytest.mark.parametrize("which", ["small", "full"])
+def test_encoder_parity_mode_matches_reference_semantics_oracle(dev, full_std, which):
+    """AudioEncoder.precision = "fp32": float32 activations end to end, as the reference (audio.py:278 + encoder.py:272-323).
+    Against the oracle WITHOUT the GPU's rounding points the features must agree to fp32 accuracy -- two orders of magnitude
+    tighter than the fast path's bound."""
+    import oracle
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    if which == "small":
+        cfg = synth.small_config()
+        state = synth.random_state(cfg, seed=8, bias_std=0.02, norm_jitter=0.1)
+        model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
+        clips, atol = [signal("speechlike", n, seed=60 + i) for i, n in enumerate((16000, 48077, 480000))], 2e-5
+    else:
+        cfg, state, model = full_std
+        clips, atol = [signal("speechlike", 80000, seed=75), signal("speechlike", 480000, seed=76)], 2e-4
+    enc_ref = _oracles(cfg, state)["reference"][0]
+    res = {}
+    try:
+        for x in clips:
+            mel = q.log_mel_spectrogram(x)
+            ref = enc_ref(oracle.log_mel_spectrogram(x))
+            model._encoder.precision = "fp32"
+            got = model._encoder(mel)[0].cpu()
+            model._encoder.precision = "bf16"
+            fast = model._encoder(mel)[0].cpu()
+            assert got.shape == ref.shape
+            res[f"{len(x) / 16000:g}s"] = {"parity_max": float((got - ref).abs().max()), "parity_mean": float((got - ref).abs().mean()),
+                                         "fast_max": float((fast - ref).abs().max()), "fast_mean": float((fast - ref).abs().mean()),
+                                         "ref_absmax": float(ref.abs().max())}
+    finally:
+        model._encoder.precision = "bf16"
+    _record(f"encoder_parity_mode_{which}", res)
+    for k, r in res.items():
+        assert r["parity_max"] <= atol, (k, r)
+        assert r["parity_max"] * 20 < r["fast_max"], (k, r)            # the fp32 mode really is a different regime
+
+
+def test_fast_vs_parity_mode_token_agreement(dev, full_wide):
+    """1.7B shapes, 4 clips x 128 greedy tokens: encoder in the fast (bf16 operands) and in the reference-semantics (fp32)
+    mode.  Recorded: token agreement between the two modes, and each mode's margin-aware agreement with the
+    reference-semantics oracle (fp32 encoder activations, unrounded softmax probabilities)."""
+    cfg, state, model = full_wide
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    clips = [signal("speechlike", n, seed=500 + i) for i, n in enumerate((80000, 192000, 480000, 480000))]
+    fast = model.generate_tokens(clips, [128] * 4, "English", repetition_penalty=1.2)
+    try:
+        model._encoder.precision = "fp32"
+        tot = _run_margin_case(model, cfg, state, clips, 128, 1.2, ULPS_FULL, "full_wide_embed_512_parity_encoder")
+        par = model.generate_tokens(clips, [128] * 4, "English", repetition_penalty=1.2)
+    finally:
+        model._encoder.precision = "bf16"
+    same = sum(a == b for ta, tb in zip(fast, par) for a, b in zip(ta, tb))
+    first_div = [next((i for i, (a, b) in enumerate(zip(ta, tb)) if a != b), len(ta)) for ta, tb in zip(fast, par)]
+    _record("fast_vs_parity_encoder_tokens", {"n": 512, "same_position_tokens": same, "rate": round(same / 512, 4),
+                                              "first_divergence_per_clip": first_div})
+    r = tot["reference"]
+    assert r["decisive_exact_rate"] >= 0.99 and tot["gpu_rounding"]["decisive_exact"] == tot["gpu_rounding"]["decisive"]
+
+
 # ----------------------------------------------------------------------------- BASELINE.json configs[4] at full size
 def test_config5_full_size_longform_fp8_sampling(dev):
     """Qwen3-ASR-1.7B shapes, fp8 weights, 20 min of audio with chunk_duration=30 (low-energy split, reference
