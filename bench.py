@@ -131,8 +131,9 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the batches-in-flight throughput leg")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight in the throughput leg (host threads / lanes)")
-    ap.add_argument("--weights", choices=("bf16", "fp8"), default="bf16",
-                    help="fp8: decoder weights quantised on load (BASELINE.json configs[4]; not the headline config)")
+    ap.add_argument("--weights", choices=("bf16", "fp8", "fp8w"), default="bf16",
+                    help="fp8: decoder weights quantised on load, prefill on the fp8 MFMA (BASELINE.json configs[4]; not the headline "
+                         "config); fp8w: weight-only variant")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the ndec=1500 and 5 s secondary legs")
     args = ap.parse_args()
 
@@ -251,7 +252,8 @@ def main() -> None:
         "metric": "real-time factor (audio-sec/wall-sec), Qwen3-ASR-1.7B bf16 30s clips",
         "value": audio_s / elapsed, "unit": "audio-s/wall-s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.weights == "bf16" else "bf16 activations, fp8-e4m3 decoder weights", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp8": "fp8-e4m3 decoder weights; prefill fp8 x fp8 MFMA, decode bf16 activations",
+                  "fp8w": "bf16 activations, fp8-e4m3 decoder weights"}[args.weights], "data": "synthetic",
         "config": {"workload": f"Qwen3-ASR-1.7B bf16, batch={B}/GPU, {args.clip_seconds:g} s clips, greedy (repetition_penalty 1.2), "
                                f"{args.ndec} decoded tokens/clip, hipGraph decode, detokenised" +
                                ("" if world == 1 else f", {world}-GPU DP (dist.run_sharded: scatter/gather over RCCL)"),

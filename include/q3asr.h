@@ -82,6 +82,18 @@ int q3asr_layernorm_f32_split3(const float* x, const float* w, const float* b, v
 int q3asr_attn_fwd_f32(const float* qkv, int64_t ld, int d_model, const int32_t* seg_start, const int32_t* seg_len, int n_segs,
                        int max_len, int n_heads, float scale, float* out, int64_t ldo, void* stream);
 
+/* ---- fp8 (OCP e4m3) GEMM on v_mfma_f32_16x16x32_fp8_fp8 (BASELINE.json configs[4]: prefill projections of
+ * decoder.py:92-97,136-165 with fp8 weights): C = (A8 . W8^T) * a_scale[m] * w_scale[n] -> bf16 [M][ldo].
+ * A8 bytes [M][lda] (per-token scale a_scale[M], from the two quantisers below), W8 bytes [N][ldw] (per-row scale w_scale[N]).
+ * act: 0 none, 2 SwiGLU (weights interleaved as for q3asr_gemm_bf16); res_kind: 0 none, 2 bf16 residual. */
+int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
+                   int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo, void* stream);
+/* RMSNorm (decoder.py:189,194) with the bf16 result quantised per row: y8 = e4m3(y / scale[m]), scale = max|y| / 448 */
+int q3asr_rmsnorm_bf16_fp8(const void* x, int64_t ldx, const void* w, void* y8, int64_t ldy, float* scale, int M, int D, float eps,
+                           void* stream);
+/* per-row quantisation of a bf16 matrix (attention output, SwiGLU output) */
+int q3asr_quantize_rows_fp8(const void* x, int64_t ldx, void* y8, int64_t ldy, float* scale, int M, int D, void* stream);
+
 /* ---- nn.RMSNorm (decoder.py:189,194,251): bf16 -> bf16; row_idx optional source-row gather -- */
 int q3asr_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, const int32_t* row_idx,
                        int M, int D, float eps, void* stream);

@@ -26,6 +26,9 @@ _SIGS = {
     "q3asr_attn_fwd_f32": [_vp, _i64, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i64, _vp],
     "q3asr_conv3x3s2_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _vp],
     "q3asr_gemm_bf16": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _i, _i64, _vp, _vp],
+    "q3asr_gemm_fp8": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _i64, _vp, _i64, _vp],
+    "q3asr_rmsnorm_bf16_fp8": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _f, _vp],
+    "q3asr_quantize_rows_fp8": [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp],
     "q3asr_layernorm_f32_bf16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_rmsnorm_bf16": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _f, _vp],
     "q3asr_attn_fwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],

@@ -34,6 +34,8 @@ struct GemmParams {
     void* out; int out_kind; long ldo;                        // 0 bf16, 1 fp32
     const int* row_map;      // optional destination row per m (<0: skip)
     int lds_epi;             // 8-phase kernel: epilogue through the wave-private LDS transpose (host-checked preconditions)
+    // fp8 (OCP e4m3) operands on v_mfma_f32_16x16x32_fp8_fp8 (q3asr_gemm_fp8): A and W are bytes, C = (A8 . W8^T) * a_scale[m] * w_scale[n]
+    const float* a_scale; const float* w_scale;
 };
 
 // 128-byte rows: two rows make one 256-byte bank row, so the XOR uses row >> 1 and the row parity supplies the 4th bit:
@@ -564,7 +566,7 @@ __device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile, int tm0, int
     const int kt = min(ktile, c.nk - 1);
     constexpr int h = KIND >> 1;
     char* dst = c.ring + SLOT * G8_SLOT + c.wave_lds;
-    if constexpr (!CONV) {
+    if constexpr (CONV != 1) {                                              // plain rows (bf16: 64 k per 128-byte tile row; fp8: 128 k)
         const unsigned kb = (unsigned)kt * 128u + 2u * c.kslot[0];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -621,16 +623,28 @@ __device__ __forceinline__ void g8_read_b(const G8Ctx& c, bf16x8 (&bf)[2][2]) {
         bf[jj][1] = *reinterpret_cast<const bf16x8*>(b + ((c.rdB + jj * 2048) ^ 64u));
     }
 }
-template <int MH, int NH>
+template <int MH, int NH, bool F8 = false>
 __device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][8], const bf16x8 (&af)[4][2], const bf16x8 (&bf)[2][2]) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-                acc[NH * 2 + jj][MH * 4 + ii] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jj][kk], af[ii][kk], acc[NH * 2 + jj][MH * 4 + ii], 0, 0, 0);
+            for (int jj = 0; jj < 2; ++jj) {
+                if constexpr (F8) {
+                    // a 16-byte fragment = two 8-byte fp8 operands: the same byte ranges of a tile row feed both sides, i.e. one
+                    // permutation of k applied to A and W alike, which a sum over k does not see
+                    typedef long l64x2 __attribute__((ext_vector_type(2)));
+                    const l64x2 wb = __builtin_bit_cast(l64x2, bf[jj][kk]), ab = __builtin_bit_cast(l64x2, af[ii][kk]);
+                    f32x4 t = acc[NH * 2 + jj][MH * 4 + ii];
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[0], ab[0], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[1], ab[1], t, 0, 0, 0);
+                    acc[NH * 2 + jj][MH * 4 + ii] = t;
+                } else {
+                    acc[NH * 2 + jj][MH * 4 + ii] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jj][kk], af[ii][kk], acc[NH * 2 + jj][MH * 4 + ii], 0, 0, 0);
+                }
+            }
 }
 
 // One phase.  PH = g & 7; `tile` = K tile whose half-tile S[g+7] is issued ((g + 7) >> 2).
@@ -648,10 +662,10 @@ __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    if constexpr ((PH & 3) == 0) g8_mfma<0, 0>(acc, af, b0cur);
-    else if constexpr ((PH & 3) == 1) g8_mfma<0, 1>(acc, af, b1);
-    else if constexpr ((PH & 3) == 2) g8_mfma<1, 1>(acc, af, b1);
-    else g8_mfma<1, 0>(acc, af, b0cur);
+    if constexpr ((PH & 3) == 0) g8_mfma<0, 0, CONV == 2>(acc, af, b0cur);
+    else if constexpr ((PH & 3) == 1) g8_mfma<0, 1, CONV == 2>(acc, af, b1);
+    else if constexpr ((PH & 3) == 2) g8_mfma<1, 1, CONV == 2>(acc, af, b1);
+    else g8_mfma<1, 0, CONV == 2>(acc, af, b0cur);
     __builtin_amdgcn_s_setprio(0);
     G8_BAR();
 }
@@ -660,7 +674,7 @@ __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0
 // keeps turning across the seam, so the first seven half-tiles of the next output tile are already in flight while the
 // last phases of the current one compute and while the epilogue stores; the wave rows re-align for the epilogue and
 // stagger again after it.  The conv variant takes one tile per workgroup (its per-row im2col state is per tile).
-template <int CONV>
+template <int CONV>      // 0: plain bf16, 1: implicit-GEMM conv (bf16), 2: plain fp8 (e4m3 x e4m3, scales in the epilogue)
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem8[];          // the only LDS object: 8 ring slots x 16 KiB + 8 x 4 KiB epilogue staging
     const int tid = threadIdx.x, lane = tid & 63;
@@ -685,10 +699,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
     c.W = reinterpret_cast<const char*>(p.W);
     c.ring = smem8;
     c.wave_lds = wave * 1024;
-    c.nk = CONV ? (((p.K + BK - 1) / BK + 1) & ~1) : p.K / BK;              // conv: K padded with zero taps to an even tile count
+    c.nk = CONV == 1 ? (((p.K + BK - 1) / BK + 1) & ~1) : (CONV == 2 ? p.K / 128 : p.K / BK);   // conv: K padded with zero taps to an even tile count; fp8: 128 k per tile
     c.Hin = p.Hin; c.Win = p.Win; c.Cin = p.Cin; c.K = p.K;
     c.M = p.M; c.N = p.N;
-    c.lda2 = (unsigned)(p.lda * 2); c.ldw2 = (unsigned)(p.ldw * 2);
+    c.lda2 = (unsigned)(p.lda * (CONV == 2 ? 1 : 2)); c.ldw2 = (unsigned)(p.ldw * (CONV == 2 ? 1 : 2));
     {
         const int rr = 8 * wave + (lane >> 3);                              // q*64 + rr = row of the half-tile image this lane fills
         c.rr = rr;
@@ -701,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             c.offA[h][q] = c.offW[h][q] = c.ahw[h][q] = 0;
-            if constexpr (CONV) {
+            if constexpr (CONV == 1) {
                 const int r = 64 * q + c.rr;
                 const int rowA = min(m0 + (r >> 6) * 128 + h * 64 + (r & 63), p.M - 1);
                 const int rowW = min(n0 + (r >> 5) * 64 + h * 32 + (r & 31), p.N - 1);
@@ -745,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
         if (wr == 1) G8_BAR();                                             // the second wave row runs one barrier behind
         for (int it = 0; it < iters; ++it) {
             const int t2 = 2 * it;
-            const bool seam = !CONV && it == last_it;                      // uniform: issues beyond this tile's K belong to the next tile
+            const bool seam = CONV != 1 && it == last_it;                  // uniform: issues beyond this tile's K belong to the next tile
             const int im0 = seam ? m0n : m0, in0 = seam ? n0n : n0;
             const int wrap = seam ? c.nk : 0;
             g8_phase<0, CONV>(c, t2 + 1, m0, n0, acc, af, b1, b0e, b0o);            // S[8it+7]  = A1 of tile 2it+1
@@ -758,10 +772,25 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
             g8_phase<7, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
         }
         if (wr == 0) G8_BAR();                                             // re-align the wave rows
+        if constexpr (CONV == 2) {                                          // fp8: per-token and per-weight-row scales (fp32)
+            int lane2 = lane;
+            asm volatile("" : "+v"(lane2));                                // keep these addresses out of the K loop's live ranges
+            const int g2 = lane2 >> 4, li2 = lane2 & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nb = min(n0 + wc * 64 + j * 16 + 4 * g2, p.N - 4);
+                const f32x4 sw = *reinterpret_cast<const f32x4*>(p.w_scale + nb);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float sa = p.a_scale[min(m0 + wr * 128 + i * 16 + li2, p.M - 1)];
+                    acc[j][i] *= sw * sa;
+                }
+            }
+        }
         if (p.lds_epi) gemm_epilogue_lds(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
         else gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
         v += gridDim.x;
-        if (CONV || v >= total_tiles) break;                               // uniform
+        if (CONV == 1 || v >= total_tiles) break;                          // uniform
         m0 = m0n; n0 = n0n;
         if (v + (int)gridDim.x < total_tiles) tile_origin(v + gridDim.x, m0n, n0n);
     }
@@ -895,4 +924,40 @@ extern "C" int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, i
     Q3_REQUIRE(act != 2, "conv3x3s2: SwiGLU epilogue not valid here");
     gemm_launch(p, true, (hipStream_t)stream);
     return q3_check_launch("conv3x3s2");
+}
+
+
+// ---------------------------------------------------------------------------
+// fp8 x fp8 GEMM on the CDNA4 fp8 MFMA (BASELINE.json configs[4]):  C[M,N] = (A8 . W8^T) * a_scale[m] * w_scale[n], then the
+// same epilogues as q3asr_gemm_bf16 (SwiGLU, bf16 residual).  A8 = activations quantised per token (row) to OCP e4m3 by
+// q3asr_rmsnorm_bf16_fp8 / q3asr_quantize_rows_fp8, W8 = the checkpoint weight quantised per output row at load.  Runs on the
+// 8-phase kernel: a tile row is 128 bytes = 128 k (64 for bf16), every 16-byte fragment feeds two
+// v_mfma_f32_16x16x32_fp8_fp8, so per unit of K the MFMA work is that of the bf16 kernel and the LDS / L2 / HBM operand
+// bytes are half.
+// ---------------------------------------------------------------------------
+extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
+                              int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo,
+                              void* stream) {
+    GemmParams p{};
+    p.A = (const bf16*)A8; p.lda = lda; p.W = (const bf16*)W8; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+    p.act = act; p.res = res; p.res_kind = res_kind; p.ldres = ldres; p.out = out; p.out_kind = 0; p.ldo = ldo;
+    p.a_scale = a_scale; p.w_scale = w_scale;
+    Q3_REQUIRE(A8 && W8 && a_scale && w_scale && out, "gemm_fp8: null pointer");
+    Q3_REQUIRE(M > 0 && N > 0 && K >= 256 && K % 256 == 0 && N % 8 == 0, "gemm_fp8: M=%d N=%d K=%d (K a multiple of 256, N of 8)", M, N, K);
+    Q3_REQUIRE(lda >= K && ldw >= K && lda % 16 == 0 && ldw % 16 == 0 && ((uintptr_t)A8 & 15) == 0 && ((uintptr_t)W8 & 15) == 0,
+               "gemm_fp8: rows must be 16-byte aligned (lda=%ld ldw=%ld)", (long)lda, (long)ldw);
+    Q3_REQUIRE((long)M * lda < (1L << 32) && (long)N * ldw < (1L << 32), "gemm_fp8: operand larger than 4 GiB");
+    Q3_REQUIRE((act == 0 || act == 2) && (res_kind == 0 || res_kind == 2), "gemm_fp8: epilogues are none / SwiGLU and none / bf16 residual");
+    Q3_REQUIRE(res_kind == 0 || res, "gemm_fp8: residual kind set without pointer");
+    if (act == 2) Q3_REQUIRE(N % 32 == 0 && res_kind == 0 && ldo % 8 == 0 && ldo >= N / 2, "gemm_fp8: SwiGLU needs N%%32==0, no residual, ldo >= N/2");
+    else Q3_REQUIRE(ldo % 8 == 0 && ldo >= N, "gemm_fp8: ldo=%ld must be >= N and a multiple of 8", (long)ldo);
+    Q3_REQUIRE(((uintptr_t)out & 15) == 0 && ((uintptr_t)w_scale & 15) == 0 && (res_kind == 0 || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0)),
+               "gemm_fp8: out / w_scale / res must be 16-byte aligned");
+    p.lds_epi = 1;
+    const unsigned tiles256 = (unsigned)((M + G2_T - 1) / G2_T) * (unsigned)((N + G2_T - 1) / G2_T);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS); attr = true; }
+    const bool persist = act != 2 && tiles256 > 256u;
+    hipLaunchKernelGGL(gemm8p_kernel<2>, dim3(persist ? 256u : tiles256), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles256);
+    return q3_check_launch("gemm_fp8");
 }

@@ -110,3 +110,84 @@ extern "C" int q3asr_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, voi
     }
     return q3_check_launch("rmsnorm");
 }
+
+
+// ---------------------------------------------------------------------------
+// Per-token fp8 quantisation of a GEMM's activation operand (BASELINE.json configs[4], q3asr_gemm_fp8).
+// y8[m][k] = e4m3(v[m][k] / scale[m]),  scale[m] = max_k |v[m][k]| / 448  (1 for an all-zero row),  v = the bf16 values the
+// bf16 path would feed the GEMM (RMSNorm output, decoder.py:189,194 / attention output / SwiGLU output).
+// One wave per row; the row is read twice (the second time from L1 / L2).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
+template <bool NORM>
+__global__ __launch_bounds__(256) void rows_to_fp8_kernel(const bf16* __restrict__ x, long ldx, const bf16* __restrict__ w, float eps,
+                                                          unsigned char* __restrict__ y8, long ldy, float* __restrict__ scale, int M, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const bf16x8* xr = reinterpret_cast<const bf16x8*>(x + (long)row * ldx);
+    const int nv = D >> 3;
+    float r = 1.0f;
+    if (NORM) {
+        float q = 0.f;
+        for (int i = lane; i < nv; i += 64) {
+            const bf16x8 v = xr[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = bf2f(v[e]); q = fmaf(f, f, q); }
+        }
+        r = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    }
+    float amax = 0.f;
+    for (int i = lane; i < nv; i += 64) {
+        const bf16x8 v = xr[i];
+        bf16x8 wv;
+        if (NORM) wv = reinterpret_cast<const bf16x8*>(w)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = NORM ? round_bf(bf2f(v[e]) * r * bf2f(wv[e])) : bf2f(v[e]);
+            amax = fmaxf(amax, fabsf(f));
+        }
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2* yr = reinterpret_cast<u32x2*>(y8 + (long)row * ldy);
+    for (int i = lane; i < nv; i += 64) {
+        const bf16x8 v = xr[i];
+        bf16x8 wv;
+        if (NORM) wv = reinterpret_cast<const bf16x8*>(w)[i];
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (NORM ? round_bf(bf2f(v[e]) * r * bf2f(wv[e])) : bf2f(v[e])) * inv;
+        yr[i] = u32x2{pack4_fp8(f[0], f[1], f[2], f[3]), pack4_fp8(f[4], f[5], f[6], f[7])};
+    }
+}
+
+static int rows_to_fp8_check(const char* who, const void* x, int64_t ldx, void* y8, int64_t ldy, float* scale, int M, int D) {
+    Q3_REQUIRE(x && y8 && scale, "%s: null pointer", who);
+    Q3_REQUIRE(M > 0 && D > 0 && D % 8 == 0 && ldx >= D && ldx % 8 == 0 && ldy >= D && ldy % 8 == 0, "%s: M=%d D=%d ldx=%ld ldy=%ld", who, M, D, (long)ldx, (long)ldy);
+    return Q3_OK;
+}
+
+extern "C" int q3asr_rmsnorm_bf16_fp8(const void* x, int64_t ldx, const void* w, void* y8, int64_t ldy, float* scale, int M, int D, float eps,
+                                      void* stream) {
+    if (int rc = rows_to_fp8_check("rmsnorm_bf16_fp8", x, ldx, y8, ldy, scale, M, D)) return rc;
+    Q3_REQUIRE(w, "rmsnorm_bf16_fp8: null weight");
+    hipLaunchKernelGGL(rows_to_fp8_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (long)ldx, (const bf16*)w, eps,
+                       (unsigned char*)y8, (long)ldy, scale, M, D);
+    return q3_check_launch("rmsnorm_bf16_fp8");
+}
+
+extern "C" int q3asr_quantize_rows_fp8(const void* x, int64_t ldx, void* y8, int64_t ldy, float* scale, int M, int D, void* stream) {
+    if (int rc = rows_to_fp8_check("quantize_rows_fp8", x, ldx, y8, ldy, scale, M, D)) return rc;
+    hipLaunchKernelGGL(rows_to_fp8_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (long)ldx, (const bf16*)nullptr, 0.f,
+                       (unsigned char*)y8, (long)ldy, scale, M, D);
+    return q3_check_launch("quantize_rows_fp8");
+}

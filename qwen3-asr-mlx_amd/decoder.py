@@ -156,10 +156,14 @@ class TextDecoder:
         """W: checkpoint tensors with the ``model.`` prefix stripped (reference decoder.py:282-290).
         Strict key set.  The lm_head is tied to embed_tokens (decoder.py:252).
         weight_dtype "fp8" (BASELINE.json configs[4]): projection and embedding weights are quantised on
-        load to OCP e4m3 with a power-of-two scale per output row; prefill uses the exactly-equal bf16
-        values, the decode step streams the fp8 bytes (half the HBM traffic)."""
-        if weight_dtype not in ("bf16", "fp8"):
-            raise ValueError(f"weight_dtype must be 'bf16' or 'fp8', got {weight_dtype!r}")
+        load to OCP e4m3 with a power-of-two scale per output row.  The decode step streams the fp8 bytes
+        (half the HBM traffic, widened to bf16 in registers); the prefill projections run fp8 x fp8 on the
+        CDNA4 fp8 MFMA (q3asr_gemm_fp8) with the activations quantised per token, and no bf16 copy of the
+        layer weights is kept.  "fp8w" is the weight-only variant (prefill on bf16 MFMAs over the
+        exactly-equal bf16 values, which it keeps beside the fp8 bytes): the comparison point for what the
+        activation quantisation costs in accuracy."""
+        if weight_dtype not in ("bf16", "fp8", "fp8w"):
+            raise ValueError(f"weight_dtype must be 'bf16', 'fp8' or 'fp8w', got {weight_dtype!r}")
         self.weight_dtype = weight_dtype
         import torch
         cfg = self.config
@@ -179,18 +183,21 @@ class TextDecoder:
             return t.to(device=dev, dtype=torch.bfloat16).contiguous()
 
         I = cfg.intermediate_size
-        fp8 = weight_dtype == "fp8"
+        fp8 = weight_dtype in ("fp8", "fp8w")
+        self.fp8_prefill = weight_dtype == "fp8"            # prefill projections on the fp8 MFMA (activations quantised per token)
 
-        def stream_form(dst: dict, name: str, mat):
-            """dst[name] = row-major bf16 (prefill / gather), dst[name+'16'] = decode streaming layout."""
+        def stream_form(dst: dict, name: str, mat, keep_bf16: bool = False):
+            """dst[name] = row-major operand of the prefill GEMM (bf16, or fp8 bytes in "fp8" mode), dst[name+'16'] = decode
+            streaming layout, dst[name+'_s'] = per-row scale.  keep_bf16: the embedding, whose rows are also gathered."""
             if fp8:
                 q8, scale, w_eff = ops.quantize_fp8_rows(mat)
-                dst[name], dst[name + "16"], dst[name + "_s"] = w_eff.contiguous(), ops.to_w16f8(q8), scale
+                dst[name + "16"], dst[name + "_s"] = ops.to_w16f8(q8), scale
+                dst[name] = w_eff.contiguous() if (keep_bf16 or not self.fp8_prefill) else q8.contiguous()
             else:
                 dst[name], dst[name + "16"], dst[name + "_s"] = mat, ops.to_w16(mat), None
 
         w = {"norm": bf(W["norm.weight"]), "layers": []}
-        stream_form(w, "embed", bf(W["embed_tokens.weight"]))
+        stream_form(w, "embed", bf(W["embed_tokens.weight"]), keep_bf16=True)
         for i in range(cfg.num_hidden_layers):
             p = f"layers.{i}."
             gate, up = W[p + "mlp.gate_proj.weight"].to(dev), W[p + "mlp.up_proj.weight"].to(dev)
@@ -256,6 +263,29 @@ class TextDecoder:
         att = torch.empty((M, qd), dtype=bf16, device=dev)
         act = torch.empty((M, I), dtype=bf16, device=dev)
         eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
+        if getattr(self, "fp8_prefill", False):
+            # BASELINE.json configs[4]: every projection fp8 x fp8 on the fp8 MFMA.  Activations are quantised per token where
+            # the bf16 path would hand them to the GEMM: RMSNorm output (fused), attention output, SwiGLU output.
+            u8, f32 = torch.uint8, torch.float32
+            x8 = torch.empty((M, H), dtype=u8, device=dev)
+            a8 = torch.empty((M, qd), dtype=u8, device=dev)
+            c8 = torch.empty((M, I), dtype=u8, device=dev)
+            sx, sa_, sc = (torch.empty((M,), dtype=f32, device=dev) for _ in range(3))
+            for li, L in enumerate(w["layers"]):
+                ops.rmsnorm_fp8(h, L["ln1"], x8, sx, M, H, eps)
+                ops.gemm_fp8(x8, sx, L["wqkv"], L["wqkv_s"], M, qkvd, H, qkv)
+                ops.call("q3asr_qk_norm_rope_kv", ops.ptr(qkv), 0, qkvd, 0, 0, ops.ptr(pl["row_b"]), ops.ptr(pl["row_pos"]),
+                         ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(q), ops.ptr(cache.k[li]),
+                         ops.ptr(cache.v[li]), M, nh, nkv, hd, Lmax, ops.sp())
+                ops.attn_fwd(ops.ptr(q), qd, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), pl["kv_off"], Lmax * hd, hd, att, qd,
+                             pl["seg_start"], pl["seg_len"], len(seq_lens), pl["max_len"], nh, nkv, hd, True, scale)
+                ops.quantize_rows_fp8(att, a8, sa_, M, qd)
+                ops.gemm_fp8(a8, sa_, L["wo"], L["wo_s"], M, H, qd, h, res=h)
+                ops.rmsnorm_fp8(h, L["ln2"], x8, sx, M, H, eps)
+                ops.gemm_fp8(x8, sx, L["wgu"], L["wgu_s"], M, 2 * I, H, act, act=2)
+                ops.quantize_rows_fp8(act, c8, sc, M, I)
+                ops.gemm_fp8(c8, sc, L["wdown"], L["wdown_s"], M, H, I, h, res=h)
+            return pl
         for li, L in enumerate(w["layers"]):
             ops.rmsnorm(h, L["ln1"], x, M, H, eps)
             ops.gemm(x, L["wqkv"], M, qkvd, H, qkv)
@@ -302,7 +332,7 @@ class TextDecoder:
             if len(mine) > 8:                                # evict this lane's entries only: another lane may be mid-request
                 for k in mine:
                     del self._ws[k]
-            ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device, fp8=getattr(self, "weight_dtype", "bf16") == "fp8")
+            ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device, fp8=getattr(self, "weight_dtype", "bf16") != "bf16")
         return ws
 
     def batch_cache(self, B: int, Lmax: int) -> KVCache:
@@ -330,6 +360,8 @@ class TextDecoder:
         eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
         sp = ws.splits
         layers = w["layers"]
+        if self.decode_impl != "v3" and getattr(self, "fp8_prefill", False):
+            raise NotImplementedError("decode_impl 'v1' reads row-major bf16 weights; weight_dtype='fp8' keeps none (use 'fp8w')")
         if self.decode_impl == "v3":
             ops.call("q3asr_embed_norm_x16", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
                      ops.ptr(ws.x16), B, H, eps, ops.sp())

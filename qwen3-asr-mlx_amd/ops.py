@@ -35,6 +35,20 @@ def conv3x3s2(x, imgs, Hin, Win, Cin, w, Cout, bias, act, out, out_fp32=False):
     call("q3asr_conv3x3s2_bf16", ptr(x), imgs, Hin, Win, Cin, ptr(w), Cout, ptr(bias), act, ptr(out), 1 if out_fp32 else 0, Cout, None, sp())
 
 
+def gemm_fp8(A8, a_scale, W8, w_scale, M, N, K, out, act=0, res=None, ldo=None):
+    """fp8 x fp8 GEMM (csrc/gemm.hip, q3asr_gemm_fp8): bytes [M][K] x bytes [N][K] -> bf16; res: bf16 residual (MLX add)."""
+    call("q3asr_gemm_fp8", ptr(A8), K, ptr(a_scale), ptr(W8), K, ptr(w_scale), M, N, K, act, ptr(res), 2 if res is not None else 0,
+         N if res is not None else 0, ptr(out), ldo if ldo is not None else (N // 2 if act == 2 else N), sp())
+
+
+def rmsnorm_fp8(x, w, y8, scale, M, D, eps):
+    call("q3asr_rmsnorm_bf16_fp8", ptr(x), D, ptr(w), ptr(y8), D, ptr(scale), M, D, eps, sp())
+
+
+def quantize_rows_fp8(x, y8, scale, M, D):
+    call("q3asr_quantize_rows_fp8", ptr(x), D, ptr(y8), D, ptr(scale), M, D, sp())
+
+
 def split3(x, M, K, y, ldx=None):
     """fp32 [M][K] -> bf16 [M][3K] = [hi | mid | lo] (csrc/parity.hip)."""
     call("q3asr_split3_f32", ptr(x), ldx or K, ptr(y), M, K, sp())

@@ -472,12 +472,13 @@ def _effective_state(state, cfg):
 
 
 def test_fp8_weights_greedy_matches_oracle_on_dequantised_weights(dev):
+    """Weight-only fp8 ("fp8w": bf16 activations everywhere): the same arithmetic as the bf16 model on the dequantised weights."""
     import oracle
     import qwen3_asr_mlx_amd as q
     from qwen3_asr_mlx_amd import synth
     cfg = synth.small_config()
     state = {k: v.to(dev) for k, v in synth.random_state(cfg, seed=2, bias_std=0.02, norm_jitter=0.1).items()}
-    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype="fp8")
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype="fp8w")
     x = signal("speechlike", 80000, seed=21)
     toks = model.generate_tokens([x], [20], "English", repetition_penalty=1.2)[0]
     eff = {k: v.cpu() for k, v in _effective_state(state, cfg).items()}

@@ -253,6 +253,53 @@ def test_gemm_8phase_is_stable_under_load(dev):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1000, 768, 1024), (4396, 2048, 2048), (130, 1024, 6144)])
+def test_gemm_fp8_on_the_fp8_mfma(dev, M, N, K):
+    """q3asr_gemm_fp8: per-token quantised activations x per-row quantised weights on v_mfma_f32_16x16x32_fp8_fp8 against
+    the same product in float64 of the dequantised operands (exact inputs: only the fp32 accumulation order differs), plain,
+    with the bf16 residual and through SwiGLU; the quantisers against torch's e4m3 conversion."""
+    from qwen3_asr_mlx_amd import ops
+    x = rnd((M, K), dev, 70, 1.0)
+    x[3] *= 37.0                                                       # rows with very different scales
+    x[5] = 0                                                           # an all-zero row: scale 1
+    W = rnd((N, K), dev, 71, 1.0 / math.sqrt(K))
+    q8, sw, w_eff = ops.quantize_fp8_rows(W)
+    a8 = torch.empty((M, K), dtype=torch.uint8, device=dev)
+    sa = torch.empty((M,), dtype=torch.float32, device=dev)
+    ops.quantize_rows_fp8(x, a8, sa, M, K)
+    amax = x.float().abs().amax(1)
+    want_s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    torch.testing.assert_close(sa, want_s, rtol=1e-6, atol=0)
+    want_q = (x.float() * (1.0 / sa)[:, None]).to(torch.float8_e4m3fn)
+    assert torch.equal(a8.view(torch.float8_e4m3fn).float(), want_q.float())
+    a_deq = a8.view(torch.float8_e4m3fn).double() * sa.double()[:, None]
+    ref = (a_deq @ w_eff.double().T).cpu()                             # w_eff = scale * fp8 exactly
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_fp8(a8, sa, q8, sw, M, N, K, out)
+    torch.testing.assert_close(out.float().cpu(), bfr(ref.float()), atol=2e-2, rtol=8e-3)
+    hb = rnd((M, N), dev, 72)
+    out2 = torch.empty_like(out)
+    ops.gemm_fp8(a8, sa, q8, sw, M, N, K, out2, res=hb)
+    torch.testing.assert_close(out2.float().cpu(), bfr(bfr(ref.float()) + hb.float().cpu()), atol=3e-2, rtol=8e-3)
+    # SwiGLU over 16-row interleaved (gate, up) weights, as q3asr_gemm_bf16 act=2
+    I = N // 2
+    osw = torch.empty((M, I), dtype=torch.bfloat16, device=dev)
+    ops.gemm_fp8(a8, sa, q8, sw, M, N, K, osw, act=2)
+    r3 = bfr(ref.float()).reshape(M, I // 16, 2, 16)
+    g, u = r3[:, :, 0].reshape(M, I), r3[:, :, 1].reshape(M, I)
+    torch.testing.assert_close(osw.float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=2e-2, rtol=2e-2)
+    # RMSNorm fused quantiser == rmsnorm_bf16 followed by the plain quantiser
+    if K in (1024, 2048):
+        wn = rnd((K,), dev, 73) + 1
+        y = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
+        ops.rmsnorm(x, wn, y, M, K, 1e-6)
+        b8, sb = torch.empty_like(a8), torch.empty_like(sa)
+        ops.quantize_rows_fp8(y, b8, sb, M, K)
+        c8, sc = torch.empty_like(a8), torch.empty_like(sa)
+        ops.rmsnorm_fp8(x, wn, c8, sc, M, K, 1e-6)
+        assert torch.equal(b8, c8) and torch.equal(sb, sc)
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from qwen3_asr_mlx_amd import ops
     A = rnd((4, 60), dev, 1)

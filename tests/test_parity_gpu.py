@@ -272,6 +272,65 @@ def test_fast_vs_parity_mode_token_agreement(dev, full_wide):
     assert r["decisive_exact_rate"] >= 0.99 and tot["gpu_rounding"]["decisive_exact"] == tot["gpu_rounding"]["decisive"]
 
 
+# ----------------------------------------------------------------------------- fp8 MFMA prefill (configs[4]) against the dequantised-weight oracle
+def _fp8_effective_state(state):
+    from qwen3_asr_mlx_amd import ops
+    out = dict(state)
+    for k, v in state.items():
+        if k.startswith("model.") and (k.endswith("_proj.weight") or k == "model.embed_tokens.weight"):
+            out[k] = ops.quantize_fp8_rows(v)[2]
+    return out
+
+
+@pytest.mark.parametrize("which", ["small", "full"])
+def test_fp8_mfma_prefill_agreement_with_dequantised_weight_oracle(dev, which):
+    """weight_dtype="fp8": prefill projections fp8 x fp8 on the fp8 MFMA with per-token activation scales (decode steps keep
+    bf16 activations).  Measured against the oracle on the dequantised weights (bf16 activations): last-position logits and
+    margin-aware token agreement, beside the weight-only variant "fp8w" on the same checkpoint.  What per-token e4m3
+    activations cost is recorded; the assertion only bounds it."""
+    import oracle
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    from qwen3_asr_mlx_amd.config import ModelConfig
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    if which == "small":
+        cfg = synth.small_config()
+        state = synth.random_state(cfg, seed=2, device=dev, bias_std=0.02, norm_jitter=0.1)
+        clips = [signal("speechlike", n, seed=700 + i) for i, n in enumerate((80000, 160000, 240000, 480000))]
+        ulps = ULPS_SMALL
+    else:
+        cfg = ModelConfig()
+        state = synth.random_state(cfg, seed=0, device=dev, embed_std=0.08)
+        clips = [signal("speechlike", n, seed=700 + i) for i, n in enumerate((80000, 480000))]
+        ulps = ULPS_FULL
+    eff = {k: v.cpu() for k, v in _fp8_effective_state(state).items()}
+    res = {}
+    for mode in ("fp8w", "fp8"):
+        model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype=mode)
+        got, _ = _gpu_prefill_logits(model, clips[-1])
+        enc, dec = _oracles(cfg, eff)["gpu_rounding"]
+        f_ref = enc(oracle.log_mel_spectrogram(clips[-1]))
+        dec.reset()
+        ref = dec.forward(oracle.prepare_inputs(f_ref, oracle.build_prompt(f_ref.shape[0], [6364]), dec.W["embed_tokens.weight"]))[-1]
+        oracles = {"gpu_rounding": (enc, dec)}
+        toks_all = model.generate_tokens(clips, [128] * len(clips), "English", repetition_penalty=1.2)
+        tot = {"n": 0, "exact": 0, "decisive": 0, "decisive_exact": 0, "max_gap_in_tol_units": 0.0}
+        for x, toks in zip(clips, toks_all):
+            st = _margin_check(_teacher_forced_logits(dec, enc(oracle.log_mel_spectrogram(x)), toks), toks, 1.2, ulps, strict=False)
+            for k, v in st.items():
+                tot[k] = max(tot[k], v) if k.startswith("max") else tot[k] + v
+        res[mode] = {"logit_max_diff": round(float((got - ref).abs().max()), 4), "logit_mean_diff": round(float((got - ref).abs().mean()), 5),
+                     "logit_absmax": round(float(ref.abs().max()), 3), "same_argmax": bool(int(got.argmax()) == int(ref.argmax())),
+                     "tokens": tot["n"], "exact_rate": round(tot["exact"] / tot["n"], 4), "decisive": tot["decisive"],
+                     "decisive_exact_rate": round(tot["decisive_exact"] / max(1, tot["decisive"]), 4),
+                     "max_gap_in_tol_units": round(tot["max_gap_in_tol_units"], 2), "tol_ulps": ulps}
+        del model
+    _record(f"fp8_mfma_prefill_{which}", res)
+    assert res["fp8w"]["decisive_exact_rate"] == 1.0                      # weight-only: same arithmetic as the oracle
+    assert res["fp8"]["logit_mean_diff"] < 10 * max(res["fp8w"]["logit_mean_diff"], 0.01)
+    assert res["fp8"]["decisive_exact_rate"] >= 0.8
+
+
 # ----------------------------------------------------------------------------- BASELINE.json configs[4] at full size
 def test_config5_full_size_longform_fp8_sampling(dev):
     """Qwen3-ASR-1.7B shapes, fp8 weights, 20 min of audio with chunk_duration=30 (low-energy split, reference
