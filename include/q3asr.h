@@ -65,6 +65,8 @@ int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int 
 /* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 128 = 128x128 tile, 256 = 256x256 register-staged,
  * 8 = 256x256 8-phase LDS-DMA pipeline where its preconditions hold).  All kernels give bit-identical results. */
 int q3asr_gemm_force_kernel(int mode);
+/* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
+int q3asr_gemm_set_stamp(void* buf);
 
 /* ---- nn.LayerNorm (encoder.py:112,117,319): x fp32 [M][D] -> y bf16 [M][D] ------------------ */
 int q3asr_layernorm_f32_bf16(const float* x, const float* w, const float* b, void* y, int M, int D, float eps,

@@ -36,6 +36,7 @@ struct GemmParams {
     int lds_epi;             // 8-phase kernel: epilogue through the wave-private LDS transpose (host-checked preconditions)
     // fp8 (OCP e4m3) operands on v_mfma_f32_16x16x32_fp8_fp8 (q3asr_gemm_fp8): A and W are bytes, C = (A8 . W8^T) * a_scale[m] * w_scale[n]
     const float* a_scale; const float* w_scale;
+    unsigned long long* stamp;   // diagnostic (q3asr_gemm_set_stamp): workgroup 0 records wall_clock64() at its phase boundaries
 };
 
 // 128-byte rows: two rows make one 256-byte bank row, so the XOR uses row >> 1 and the row parity supplies the 4th bit:
@@ -740,6 +741,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
 
     f32x4 acc[4][8];
     bf16x8 af[4][2], b1[2][2], b0e[2][2], b0o[2][2];
+    int n_stamp = 0;
+#define G8_STAMP() do { if (p.stamp && blockIdx.x == 0 && tid == 0 && n_stamp < 16) p.stamp[n_stamp++] = wall_clock64(); } while (0)
+    G8_STAMP();                                                             // 0: entry (after the address setup)
 
     // ---- prologue: S[0..6] in flight, S[0] (B0 of tile 0) and S[1] landed before the first reads
     g8_issue<0, 0, CONV>(c, 0, m0, n0); g8_issue<1, 1, CONV>(c, 0, m0, n0); g8_issue<2, 2, CONV>(c, 0, m0, n0);
@@ -748,6 +752,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     G8_BAR();
     g8_read_b<0>(c, b0e);
+    G8_STAMP();                                                             // 1: pipeline filled
 
     const int iters = c.nk >> 1;                                            // two K tiles (8 phases) per trip
     const int last_it = iters - 1;                                          // the DMA runs 7 half-tiles ahead: the last trip feeds the next tile
@@ -772,6 +777,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
             g8_phase<7, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
         }
         if (wr == 0) G8_BAR();                                             // re-align the wave rows
+        G8_STAMP();                                                         // 2 + 2t: K loop of tile t done
         if constexpr (CONV == 2) {                                          // fp8: per-token and per-weight-row scales (fp32)
             int lane2 = lane;
             asm volatile("" : "+v"(lane2));                                // keep these addresses out of the K loop's live ranges
@@ -789,6 +795,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
         }
         if (p.lds_epi) gemm_epilogue_lds(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
         else gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
+        G8_STAMP();                                                         // 3 + 2t: epilogue of tile t issued
         v += gridDim.x;
         if (CONV == 1 || v >= total_tiles) break;                          // uniform
         m0 = m0n; n0 = n0n;
@@ -798,6 +805,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
 }
 
 static int g_gemm_mode = -1;                                 // Q3ASR_GEMM or q3asr_gemm_force_kernel
+static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_stamp
+
+// Diagnostic hook: workgroup 0 of every following 8-phase launch writes up to 16 wall_clock64() stamps (100 MHz) to `buf`
+// (device memory, 16 x 8 bytes): entry, pipeline filled, then per tile "K loop done" / "epilogue issued".  nullptr switches
+// it off.  tools/gemm_stamps.py prints where a tile's time goes.
+extern "C" int q3asr_gemm_set_stamp(void* buf) { g_gemm_stamp = (unsigned long long*)buf; return 0; }
 
 extern "C" int q3asr_gemm_force_kernel(int mode) {
     Q3_REQUIRE(mode == 0 || mode == 128 || mode == 256 || mode == 8, "gemm_force_kernel: mode %d (0 auto, 128, 256, 8 = 8-phase)", mode);
@@ -827,6 +840,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
         // 128^2 kernel as a second launch -- fc1 142.5 -> 139.4 us, encoder qkv 88.7 -> 95.3 us, prefill qkv 200.6 -> 198.7 us: a
         // K = 1024 tile of the 128^2 kernel plus the extra launch costs what the idle CUs of the last round cost.  Not kept.
         GemmParams p8 = p;
+        p8.stamp = g_gemm_stamp;
         static const int epi_env = [] { const char* e = getenv("Q3ASR_GEMM_LDS_EPI"); return e ? atoi(e) : 1; }();
         const long esz = p.out_kind == 1 ? 4 : 2;
         p8.lds_epi = epi_env && p.N % 8 == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0 && (p.ldo * esz) % 16 == 0 &&

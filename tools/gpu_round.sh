@@ -30,6 +30,9 @@ for step in "$@"; do
     tests_all)    run 1100 $O/${TAG}_tests_all.log python3 -m pytest $R/tests -m gpu -q -x ; tail -5 $O/${TAG}_tests_all.log ;;
     bench)        run 600 $O/${TAG}_bench.err python3 $R/bench.py --steps 20 --warmup 3 ; grep '^{' $O/${TAG}_bench.err > $O/${TAG}_bench.json; grep -v '^{' $O/${TAG}_bench.err | tail -25 ;;
     benchq)       run 400 $O/${TAG}_benchq.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchq.err > $O/${TAG}_benchq.json; grep -v '^{' $O/${TAG}_benchq.err | tail -12 ;;
+    benchf8)      run 400 $O/${TAG}_benchf8.err python3 $R/bench.py --steps 5 --warmup 2 --weights fp8 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchf8.err > $O/${TAG}_benchf8.json; grep -v '^{' $O/${TAG}_benchf8.err | tail -8
+                  run 400 $O/${TAG}_benchf8w.err python3 $R/bench.py --steps 5 --warmup 2 --weights fp8w --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchf8w.err > $O/${TAG}_benchf8w.json; grep -v '^{' $O/${TAG}_benchf8w.err | tail -8 ;;
+    config5)      run 400 $O/${TAG}_config5.log python3 $R/tools/run_config5.py fp8 20 ; cat $O/${TAG}_config5.log ;;
     pmc)          prof pmc_fetch decode,encoder,prefill --pmc FETCH_SIZE --kernel-trace
                   prof pmc_write decode,encoder,prefill --pmc WRITE_SIZE --kernel-trace
                   python3 $R/tools/pmc_summary.py $(find $O/${TAG}_pmc_fetch -name '*counter_collection.csv') $(find $O/${TAG}_pmc_write -name '*counter_collection.csv') $O/${TAG}_pmc_summary.json $O/pmc_probe_meta.json > $O/${TAG}_pmc_print.txt 2>&1; tail -20 $O/${TAG}_pmc_print.txt ;;
@@ -43,6 +46,7 @@ for step in "$@"; do
     probe_regraph) prof probe_regraph regraph --pmc FETCH_SIZE --kernel-trace ;;
     bench_pmc)    rm -rf $O/${TAG}_bench_pmc; run 600 $O/${TAG}_bench_pmc.log rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_bench_pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipeline --no-extra-configs
                   find $O/${TAG}_bench_pmc -name '*.csv' -size +1M -delete; tail -12 $O/${TAG}_bench_pmc.log ;;
+    stamps)       run 300 $O/${TAG}_stamps.log python3 $R/tools/gemm_stamps.py ; cat $O/${TAG}_stamps.log ;;
     gemmk)        run 300 $O/${TAG}_gemmk.log python3 $R/tools/bench_gemm_k.py 5 ; cat $O/${TAG}_gemmk.log
                   Q3ASR_GEMM_PERSIST=0 run 300 $O/${TAG}_gemmk_np.log python3 $R/tools/bench_gemm_k.py 5 ; cat $O/${TAG}_gemmk_np.log ;;
     bench_pmc16)  rm -rf $O/${TAG}_bench_pmc16; run 600 $O/${TAG}_bench_pmc16.log rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_bench_pmc16 -- python3 $R/bench.py --steps 1 --warmup 1 --ndec 16 --no-cpu-baseline --no-pipeline --no-extra-configs
