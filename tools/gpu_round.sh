@@ -32,6 +32,7 @@ for step in "$@"; do
     benchq)       run 400 $O/${TAG}_benchq.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchq.err > $O/${TAG}_benchq.json; grep -v '^{' $O/${TAG}_benchq.err | tail -12 ;;
     benchf8)      run 400 $O/${TAG}_benchf8.err python3 $R/bench.py --steps 5 --warmup 2 --weights fp8 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchf8.err > $O/${TAG}_benchf8.json; grep -v '^{' $O/${TAG}_benchf8.err | tail -8
                   run 400 $O/${TAG}_benchf8w.err python3 $R/bench.py --steps 5 --warmup 2 --weights fp8w --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchf8w.err > $O/${TAG}_benchf8w.json; grep -v '^{' $O/${TAG}_benchf8w.err | tail -8 ;;
+    rehearse2)    Q3ASR_BENCH_REHEARSE=1 run 500 $O/${TAG}_rehearse2.err python3 $R/bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline ; grep '^{' $O/${TAG}_rehearse2.err > $O/${TAG}_rehearse2.json; grep -v '^{' $O/${TAG}_rehearse2.err | tail -12 ;;
     config5)      run 400 $O/${TAG}_config5.log python3 $R/tools/run_config5.py fp8 20 ; cat $O/${TAG}_config5.log ;;
     pmc)          prof pmc_fetch decode,encoder,prefill --pmc FETCH_SIZE --kernel-trace
                   prof pmc_write decode,encoder,prefill --pmc WRITE_SIZE --kernel-trace
