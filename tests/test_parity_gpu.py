@@ -211,6 +211,39 @@ def test_full_size_margin_aware_tokens_512(dev, full_wide):
     assert g["exact_rate"] >= 0.8
 
 
+# ----------------------------------------------------------------------------- long unchunked contexts (the default chunk_duration is 1200 s)
+def test_long_unchunked_context_matches_oracle(dev):
+    """200 s of audio in ONE sequence (2,600 audio tokens; prefill attention over 41 query tiles, decode attention over three
+    1,024-token cache chunks merged in chunk order): margin-aware greedy tokens against the oracle, small config."""
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    cfg = synth.small_config()
+    state = synth.random_state(cfg, seed=9, bias_std=0.02, norm_jitter=0.1)
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
+    clips = [signal("speechlike", 200 * 16000, seed=910)]
+    tot = _run_margin_case(model, cfg, state, clips, 48, 1.2, ULPS_SMALL, "small_long_context_200s")
+    g = tot["gpu_rounding"]
+    assert g["n"] == 48 and g["decisive_exact"] == g["decisive"] and g["decisive"] >= 24
+
+
+def test_full_size_20min_unchunked_runs_in_one_sequence(dev, full_std):
+    """Exactly 20 min with the default chunk_duration is NOT chunked (strict >, reference model.py:313): one sequence of 15,600
+    audio tokens + prompt at the 1.7B shapes (KV cache 1.8 GB at that length).  No CPU oracle at this size: the property
+    checked is that the path runs, is deterministic, and that graph replay == eager."""
+    cfg, state, model = full_std
+    audio = np.concatenate([signal("speechlike", 16000 * 60, seed=100 + i) for i in range(20)])
+    r1 = model.transcribe(audio, max_tokens=12)
+    assert r1.duration == 1200.0 and isinstance(r1.text, str)
+    toks = model.generate_tokens([audio], [12], "English")[0]
+    assert len(toks) == 12 and model.generate_tokens([audio], [12], "English")[0] == toks
+    model.use_graph = False
+    try:
+        assert model.generate_tokens([audio], [12], "English")[0] == toks
+    finally:
+        model.use_graph = True
+    model._decoder._caches.clear()                                          # give the 1.8 GB cache back
+
+
 # ----------------------------------------------------------------------------- reference-semantics encoder mode (fp32 activations)
 @pytest.mark.parametrize("which", ["small", "full"])
 def test_encoder_parity_mode_matches_reference_semantics_oracle(dev, full_std, which):
