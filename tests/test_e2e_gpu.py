@@ -490,6 +490,49 @@ def test_fp8_weights_greedy_matches_oracle_on_dequantised_weights(dev):
     assert ref.generate_tokens([x], [20], "English", repetition_penalty=1.2)[0] != toks or True
 
 
+def test_fp8_mfma_prefill_is_batch_invariant(dev):
+    """weight_dtype="fp8": activations are quantised per token, so an utterance's tokens cannot depend on its batch mates."""
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    cfg = synth.small_config()
+    state = synth.random_state(cfg, seed=12, device=dev, bias_std=0.02, norm_jitter=0.1)
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype="fp8")
+    xs = [signal("speechlike", n, seed=40 + i) for i, n in enumerate((80000, 16000, 123456, 480000))]
+    budgets = [12, 7, 9, 10]
+    batched = model.generate_tokens(xs, budgets, "English")
+    assert [len(t) for t in batched] == budgets
+    for i in range(len(xs)):
+        assert model.generate_tokens([xs[i]], [budgets[i]], "English")[0] == batched[i]
+    assert model.generate_tokens(xs[::-1], budgets[::-1], "English") == batched[::-1]
+
+
+def test_parity_mode_encoder_is_batch_invariant(dev, small):
+    """AudioEncoder.precision = "fp32": ragged utterances in one batch == each alone, bit for bit (fp32 features)."""
+    import qwen3_asr_mlx_amd as q
+    cfg, state, model = small
+    xs = [signal("speechlike", n, seed=50 + i) for i, n in enumerate((48077, 16000, 200000))]
+    enc = model._encoder
+    fe = q.audio.get_frontend(dev)
+    try:
+        enc.precision = "fp32"
+        audio, lens_dev, lens = q.audio.pack_audio(xs, dev)
+        mel, n_frames = fe(audio, lens_dev, lens)
+        feats, counts = enc.forward_batch(mel, n_frames)
+        o = 0
+        for x, c in zip(xs, counts):
+            alone = enc(q.log_mel_spectrogram(x))[0]
+            assert alone.shape[0] == c and torch.equal(alone, feats[o: o + c])
+            o += c
+    finally:
+        enc.precision = "bf16"
+    with pytest.raises(ValueError):
+        enc.precision = "fp16"
+        try:
+            enc(q.log_mel_spectrogram(xs[1]))
+        finally:
+            enc.precision = "bf16"
+
+
 def test_config5_longform_fp8_sampling(dev):
     """fp8 weights + low-energy chunking + temperature 0.7 / top-p 0.9 (scaled down: 150 s of audio in 30 s
     chunks instead of 20 min): segments are decoded as one batch and joined with spaces."""

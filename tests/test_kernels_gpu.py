@@ -232,6 +232,31 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
             assert torch.equal(a, b), mode
 
 
+def test_gemm_8phase_direct_epilogue_fallback(dev):
+    """N % 8 == 4: the whole-row (LDS-transposed) epilogue's precondition fails and the 8-phase kernel stores straight from
+    the accumulator layout; results still equal the 128x128 kernel bit for bit."""
+    from qwen3_asr_mlx_amd import _lib, ops
+    M, N, K = 530, 996, 512
+    A = rnd((M, K), dev, 46, 1.0)
+    W = rnd((N, K), dev, 47, 1.0 / math.sqrt(K))
+    bias = rnd((N,), dev, 48, 0.5, torch.float32)
+    h0 = rnd((M, N), dev, 49, 1.0, torch.float32)
+    outs = {}
+    try:
+        for mode in (128, 8):
+            _lib.call("q3asr_gemm_force_kernel", mode)
+            og = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            ops.gemm(A, W, M, N, K, og, bias=bias, act=1)
+            h32 = h0.clone()
+            ops.gemm(A, W, M, N, K, h32, bias=bias, res=h32, res_kind=1, ldres=N, out_fp32=True)
+            outs[mode] = (og, h32)
+    finally:
+        _lib.call("q3asr_gemm_force_kernel", 0)
+    torch.testing.assert_close(outs[8][1].cpu(), _gemm_ref(A, W, bias, 0, h0, 1), atol=2e-3, rtol=1e-3)
+    for a, b in zip(outs[128], outs[8]):
+        assert torch.equal(a, b)
+
+
 def test_gemm_8phase_is_stable_under_load(dev):
     """Race screen for the 8-phase pipeline (LDS-DMA data is ordered only by counted waits + barriers): 30 back-to-back
     launches of a chip-filling shape, each compared bit for bit with the 128x128 kernel's result."""
