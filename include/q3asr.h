@@ -152,6 +152,21 @@ int q3asr_skinny3_gemm_norm(const float* in_slab, int in_n_slabs, int64_t in_sla
                             const void* norm_w, float eps, int M, const void* W16, const float* w_scale, int N, int K,
                             int n_splits, int epi, int waves_per_wg, int tiles_per_wave, int wg_ksplit, float* slab,
                             void* out, int64_t ldo, void* stream);
+/* skinny4: the same product C[M, N] = X . W^T on the same W16 / W16F8 / X16 layouts (decoder.py:92-97,136-165 at T = 1, and the
+ * tied head decoder.py:252), one workgroup of `waves` waves per `tiles_per_wg` consecutive 16-row weight tiles; wave w of slab s
+ * owns k-steps [(s waves + w) ksteps_per_wave, +ksteps_per_wave) and issues all of its loads before its first MFMA; the waves'
+ * partial sums are added in wave order through LDS.  n_splits = K / (32 ksteps_per_wave waves) slabs (epi 0), which must be 1
+ * for epi 1 / 2.  Results depend on (ksteps_per_wave, waves) only, never on M or tiles_per_wg.  Instantiated geometries
+ * (tiles, k-steps, waves): epi 0 (2,2,8) (2,4,8) (2,6,8) (2,3,16); epi 1 (2,2,8) (2,8,8) (4,8,8); epi 2 (2,2,8) (4,4,16)
+ * (2,4,16); fp8 weights (w_scale != NULL) need an even k-step count; M > 32 needs waves * tiles <= 40. */
+int q3asr_skinny4_gemm(const void* X16, int M, const void* W16, const float* w_scale, int N, int K, int epi, int tiles_per_wg,
+                       int ksteps_per_wave, int waves, float* slab, void* out, int64_t ldo, void* stream);
+/* q3asr_skinny4_gemm with the residual add + RMSNorm of its activation operand fused into the prologue (M <= 2, epi 0 or 2): the
+ * arguments of q3asr_skinny3_gemm_norm, the geometry of q3asr_skinny4_gemm; bit-identical to q3asr_slab_resnorm_x16 followed by
+ * q3asr_skinny4_gemm (decoder.py:189-196 at batch 1). */
+int q3asr_skinny4_gemm_norm(const float* in_slab, int in_n_slabs, int64_t in_slab_stride, const void* h_in, void* h_out,
+                            const void* norm_w, float eps, int M, const void* W16, const float* w_scale, int N, int K, int epi,
+                            int tiles_per_wg, int ksteps_per_wave, int waves, float* slab, void* out, int64_t ldo, void* stream);
 /* h = bf16(h + bf16(sum slabs)); x16 = RMSNorm(h)*w in X16 layout (decoder.py:191-196,189,251) */
 int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
                            const void* w, void* x16, int M, int N, float eps, void* stream);

@@ -52,10 +52,13 @@ struct FuseNorm {
 };
 
 __device__ __forceinline__ void fuse_norm_prologue(const FuseNorm& f, int M, int K, bf16* xl, float* hl, float* fred, bool writer) {
+    // the first 256 threads work (the thread -> column mapping of slab_resnorm_x16_kernel); a larger workgroup's other
+    // threads only meet them at the barriers
     const int NV = K >> 3, tid = threadIdx.x;
+    const int v0 = tid < 256 ? tid : NV;
     for (int m = 0; m < M; ++m) {
         float q2 = 0.f;
-        for (int v = tid; v < NV; v += 256) {
+        for (int v = v0; v < NV; v += 256) {
             const long c0 = (long)m * K + 8 * v;
             f32x4 a0 = *reinterpret_cast<const f32x4*>(f.slab + c0), a1 = *reinterpret_cast<const f32x4*>(f.slab + c0 + 4);
             int s = 1;
@@ -82,10 +85,10 @@ __device__ __forceinline__ void fuse_norm_prologue(const FuseNorm& f, int M, int
             if (writer) *reinterpret_cast<bf16x8*>(f.h_out + c0) = ho;
         }
         q2 = wave_sum(q2);
-        if ((tid & 63) == 0) fred[tid >> 6] = q2;
+        if ((tid & 63) == 0 && tid < 256) fred[tid >> 6] = q2;
         __syncthreads();
         const float r = rsqrtf((fred[0] + fred[1] + fred[2] + fred[3]) * (1.0f / K) + f.eps);
-        for (int v = tid; v < NV; v += 256) {
+        for (int v = v0; v < NV; v += 256) {
             const bf16x8 wv = *reinterpret_cast<const bf16x8*>(f.w + 8 * v);
             bf16x8 xo;
 #pragma unroll
@@ -348,6 +351,233 @@ extern "C" int q3asr_skinny3_gemm_norm(const float* in_slab, int in_n_slabs, int
     FuseNorm f{in_slab, in_n_slabs, (long)in_slab_stride, (const bf16*)h_in, (bf16*)h_out, (const bf16*)norm_w, eps};
     return skinny3_launch("skinny3_gemm_norm", nullptr, &f, M, W16, w_scale, N, K, n_splits, epi, waves_per_wg, tiles_per_wave,
                           wg_ksplit, slab, out, ldo, stream);
+}
+
+// ---------------------------------------------------------------------------
+// skinny4: the same product on the same layouts, one fat workgroup per TPW consecutive weight tiles.
+// grid (N/16/TPW, S), WAVES waves; wave w of slab s owns the k-steps [(s WAVES + w) NKS, +NKS) of every tile of the
+// workgroup, so K is cut into S*WAVES contiguous segments of NKS steps.  A wave issues ALL of its loads -- its X fragments
+// (L2) and its NKS*TPW weight fragments (HBM, non-temporal) -- before its first MFMA: one memory round trip per launch
+// instead of skinny3's two-group pipeline, and the whole matrix is in flight from the first microsecond.  The waves'
+// partial sums meet in LDS and are added in wave order by whichever wave owns the (tile, m-tile) pair, so every output is
+//     slab_s[m][n] = ((p_{s,0} + p_{s,1}) + ...) + p_{s,WAVES-1},  p = one k-ascending MFMA chain over NKS steps,
+// a function of (NKS, WAVES, S) only: the batch size (MT) and TPW never change a bit.  M > 32 runs the m-tiles in two
+// passes over the same weight registers.  tools/micro/sk4.hip (graph of 28 dependent launches over distinct matrices, batch
+// 32, us per launch incl. the boundary, skinny3 -> skinny4): qkv 6.7 -> 5.4, o 5.1 -> 3.9, gate/up 13.4 -> 11.8-12.2,
+// down 8.4 -> 6.9, tied head 114.7 -> 109.5; batch 1: 5.6 -> 4.7, 4.5 -> 3.5, 12.3 -> 10.8, 7.2 -> 6.0, 100.3 -> 92.7; an
+// empty launch of the same grid costs 2.0.
+// ---------------------------------------------------------------------------
+// FUSE (M <= 2): the X fragments come from LDS rows that every workgroup builds for itself from the previous GEMM's slabs
+// (fuse_norm_prologue, the arithmetic of slab_resnorm_x16_kernel) while its weights are in flight.
+template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, bool FUSE = false>
+__global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restrict__ X16, const void* __restrict__ Wt, int M, int N, int K,
+                                                             const float* __restrict__ w_scale, float* __restrict__ slab,
+                                                             bf16* __restrict__ out, long ldo, const FuseNorm fz) {
+    static_assert(!F8 || NKS % 2 == 0, "fp8 fragments come in pairs of k steps");
+    static_assert(EPI != 2 || TPW % 2 == 0, "SwiGLU needs whole (gate, up) tile pairs per workgroup");
+    static_assert(!FUSE || (MT == 1 && WAVES >= 4), "fused norm: M <= 2, at least 256 threads");
+    extern __shared__ f32x4 red4[];                          // [WAVES][TPW][MT][64] | FUSE: x rows [2][K] bf16 | K floats
+    __shared__ float fred4[4];
+    constexpr int MC = MT < 2 ? MT : 2;                      // m-tiles per pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t0 = blockIdx.x * TPW;
+    const int ks0 = (blockIdx.y * WAVES + wave) * NKS;
+    const bf16* xp = X16 + (long)ks0 * MT * 512 + lane * 8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NW = F8 ? NKS / 2 : NKS;                   // weight loads per tile
+    bf16x8 w16[F8 ? 1 : NW][TPW];
+    u32x4 w8[F8 ? NW : 1][TPW];
+    bf16x8 xf[NKS][MC];
+    if constexpr (!FUSE) {
+#pragma unroll
+        for (int i = 0; i < NKS; ++i)
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc) xf[i][mc] = *reinterpret_cast<const bf16x8*>(xp + ((long)i * MT + mc) * 512);
+    }
+    if constexpr (!F8) {
+        const bf16* wp = (const bf16*)Wt + ((long)t0 * (K >> 5) + ks0) * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                w16[i][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ((long)t * (K >> 5) + i) * 512));
+    } else {
+        const char* wp = (const char*)Wt + ((long)t0 * (K >> 6) + (ks0 >> 1)) * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                w8[i][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + ((long)t * (K >> 6) + i) * 1024));
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // every load above is issued before the first MFMA below
+    if constexpr (FUSE) {
+        bf16* xl = reinterpret_cast<bf16*>(red4 + WAVES * TPW * MT * 64);
+        float* hl = reinterpret_cast<float*>(reinterpret_cast<char*>(xl) + (size_t)K * 4);
+        fuse_norm_prologue(fz, M, K, xl, hl, fred4, blockIdx.x == 0 && blockIdx.y == 0);
+        const int xrow = min(lane & 15, M - 1) * K + 8 * (lane >> 4);      // lanes of rows >= M re-read the last row (results unused)
+#pragma unroll
+        for (int i = 0; i < NKS; ++i) xf[i][0] = *reinterpret_cast<const bf16x8*>(xl + xrow + (ks0 + i) * 32);
+    }
+#pragma unroll
+    for (int m0 = 0; m0 < MT; m0 += MC) {
+        if (m0 > 0) {
+#pragma unroll
+            for (int i = 0; i < NKS; ++i)
+#pragma unroll
+                for (int mc = 0; mc < MC; ++mc) xf[i][mc] = *reinterpret_cast<const bf16x8*>(xp + ((long)i * MT + m0 + mc) * 512);
+        }
+        f32x4 acc[TPW][MC];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc) acc[t][mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!F8) {
+#pragma unroll
+            for (int i = 0; i < NKS; ++i)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                    for (int mc = 0; mc < MC; ++mc) acc[t][mc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w16[i][t], xf[i][mc], acc[t][mc], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) {
+                        const bf16x8 wf = h == 0 ? fp8x8_to_bf16(w8[i][t][0], w8[i][t][1]) : fp8x8_to_bf16(w8[i][t][2], w8[i][t][3]);
+#pragma unroll
+                        for (int mc = 0; mc < MC; ++mc) acc[t][mc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[2 * i + h][mc], acc[t][mc], 0, 0, 0);
+                    }
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc) red4[((wave * TPW + t) * MT + m0 + mc) * 64 + lane] = acc[t][mc];
+    }
+    __syncthreads();
+    // lane (g, li) of the (tile t, m-tile mt) image holds C[n = 16 (t0 + t) + 4 g + r][m = 16 mt + li]
+    const int g = lane >> 4, li = lane & 15;
+    auto total = [&](int t, int mt) {
+        f32x4 a = red4[(t * MT + mt) * 64 + lane];
+#pragma unroll
+        for (int ww = 1; ww < WAVES; ++ww) a += red4[((ww * TPW + t) * MT + mt) * 64 + lane];
+        if (F8) a *= *reinterpret_cast<const f32x4*>(w_scale + 16 * (t0 + t) + 4 * g);
+        return a;
+    };
+    if (EPI == 2) {
+        for (int c = wave; c < (TPW / 2) * MT; c += WAVES) {
+            const int p = c / MT, mt = c - p * MT;           // tile t0 + 2p = gate rows, t0 + 2p + 1 = up rows of 16 features
+            const f32x4 a = total(2 * p, mt), b = total(2 * p + 1, mt);
+            const int m = 16 * mt + li;
+            if (m >= M) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float av = round_bf(a[r]), bv = round_bf(b[r]);                   // bf16 gate/up (decoder.py:97)
+                o[r] = f2bf(av / (1.0f + __expf(-av)) * bv);
+            }
+            *reinterpret_cast<bf16x4*>(out + x16_index(m, ((t0 + 2 * p) >> 1) * 16 + 4 * g, MT)) = o;
+        }
+        return;
+    }
+    for (int c = wave; c < TPW * MT; c += WAVES) {
+        const int t = c / MT, mt = c - t * MT;
+        const f32x4 a = total(t, mt);
+        const int m = 16 * mt + li;
+        if (m >= M) continue;
+        const int n = 16 * (t0 + t) + 4 * g;
+        if (EPI == 0) {
+            *reinterpret_cast<f32x4*>(slab + ((long)blockIdx.y * M + m) * N + n) = a;
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(a[r]);
+            *reinterpret_cast<bf16x4*>(out + (long)m * ldo + n) = o;
+        }
+    }
+}
+
+template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, bool FUSE>
+static void skinny4_go(dim3 grid, hipStream_t s, const void* X16, const FuseNorm& fz, const void* W, int M, int N, int K, const float* w_scale,
+                       float* slab, void* out, long ldo) {
+    constexpr size_t image = (size_t)WAVES * TPW * MT * 64 * sizeof(f32x4);
+    static_assert(image <= 160 * 1024, "skinny4: partial-sum image exceeds LDS");
+    const size_t lds = image + (FUSE ? (size_t)K * 8 : 0);   // + two bf16 rows and K floats
+    static size_t granted = 64 * 1024;
+    if (lds > granted) {
+        (void)hipFuncSetAttribute((const void*)skinny4_kernel<MT, TPW, NKS, EPI, WAVES, F8, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        granted = lds;
+    }
+    hipLaunchKernelGGL((skinny4_kernel<MT, TPW, NKS, EPI, WAVES, F8, FUSE>), grid, dim3(64 * WAVES), lds, s, (const bf16*)X16, W, M, N, K, w_scale,
+                       slab, (bf16*)out, ldo, fz);
+}
+
+// The instantiated geometries (tiles per workgroup, k-steps per wave, waves), by epilogue; ops.gemm_geometry4 holds the same
+// list.  M > 32 takes the two-tile form of the 16-wave SwiGLU geometry (256 KiB of partial sums would not fit): same
+// (NKS, WAVES), same bits.
+
+static int skinny4_launch(const char* who, const void* X16, const FuseNorm* fuse, int M, const void* W16, const float* w_scale, int N, int K, int epi,
+                          int tiles_per_wg, int ksteps_per_wave, int waves, float* slab, void* out, int64_t ldo, void* stream) {
+    Q3_REQUIRE((X16 || fuse) && W16, "%s: null pointer", who);
+    Q3_REQUIRE(M > 0 && M <= 64 && N > 0 && N % 16 == 0 && K > 0, "%s: M=%d must be 1..64, N=%d a multiple of 16", who, M, N);
+    Q3_REQUIRE(epi >= 0 && epi <= 2, "%s: bad epi %d", who, epi);
+    const int seg = 32 * ksteps_per_wave * waves;
+    Q3_REQUIRE(seg > 0 && tiles_per_wg > 0 && K % seg == 0 && (N / 16) % tiles_per_wg == 0, "%s: K=%d not a multiple of %d or N/16=%d not of %d", who, K,
+               seg, N / 16, tiles_per_wg);
+    const int S = K / seg;
+    if (epi == 0) Q3_REQUIRE(slab, "%s: slab epilogue without workspace", who);
+    else Q3_REQUIRE(out && S == 1, "%s: direct epilogues need out and K = 32 * k-steps * waves (one slab)", who);
+    if (epi == 1) Q3_REQUIRE(ldo % 4 == 0 && ldo >= N, "%s: bad ldo", who);
+    if (w_scale) Q3_REQUIRE(ksteps_per_wave % 2 == 0, "%s: fp8 weights need an even number of k-steps per wave", who);
+    FuseNorm fz{};
+    if (fuse) {
+        fz = *fuse;
+        Q3_REQUIRE(M <= 2 && epi != 1, "%s: fused norm needs M <= 2, epi 0 or 2", who);
+        Q3_REQUIRE(fz.slab && fz.S >= 1 && fz.h_in && fz.h_out && fz.w && fz.h_in != fz.h_out && fz.slab != slab,
+                   "%s: fused norm needs its own input slabs and distinct h_in / h_out", who);
+        Q3_REQUIRE(K % 8 == 0 && (size_t)waves * tiles_per_wg * 1024 + (size_t)K * 8 <= 160 * 1024, "%s: K=%d too large for the fused activation image", who, K);
+    }
+    const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    dim3 grid(N / 16 / tiles_per_wg, S);
+    hipStream_t s = (hipStream_t)stream;
+    bool done = false;
+#define Q3_TRY(MT_, TPW_, NKS_, EPI_, WAVES_, F8_, FUSE_)                                                                              \
+    if (!done && MT == MT_ && tiles_per_wg == TPW_ && ksteps_per_wave == NKS_ && epi == EPI_ && waves == WAVES_ && (w_scale != nullptr) == F8_ && \
+        (fuse != nullptr) == FUSE_) {                                                                                                  \
+        skinny4_go<MT_, TPW_, NKS_, EPI_, WAVES_, F8_, FUSE_>(grid, s, X16, fz, W16, M, N, K, w_scale, slab, out, (long)ldo);          \
+        done = true;                                                                                                                   \
+    }
+#define Q3_TRY_F8(MT_, TPW_, NKS_, EPI_, WAVES_, FUSE_)                                 \
+    Q3_TRY(MT_, TPW_, NKS_, EPI_, WAVES_, false, FUSE_)                                 \
+    if constexpr ((NKS_) % 2 == 0) { Q3_TRY(MT_, TPW_, NKS_, EPI_, WAVES_, true, FUSE_) }
+#define Q3_TRY_MT(TPW_, NKS_, WAVES_, EPI_)                                             \
+    Q3_TRY_F8(1, TPW_, NKS_, EPI_, WAVES_, false)                                       \
+    if constexpr ((EPI_) != 1) { Q3_TRY_F8(1, TPW_, NKS_, EPI_, WAVES_, true) }         \
+    Q3_TRY_F8(2, TPW_, NKS_, EPI_, WAVES_, false)                                       \
+    if constexpr ((WAVES_) * (TPW_) * 4 <= 160) { Q3_TRY_F8(4, TPW_, NKS_, EPI_, WAVES_, false) }
+    // epilogue 0 (fp32 slabs): the projections; 1 (bf16 rows): the tied head; 2 (SwiGLU -> X16): gate/up
+    Q3_TRY_MT(2, 2, 8, 0) Q3_TRY_MT(2, 4, 8, 0) Q3_TRY_MT(2, 6, 8, 0) Q3_TRY_MT(2, 3, 16, 0)
+    Q3_TRY_MT(2, 2, 8, 1) Q3_TRY_MT(2, 8, 8, 1) Q3_TRY_MT(4, 8, 8, 1)
+    Q3_TRY_MT(2, 2, 8, 2) Q3_TRY_MT(4, 4, 16, 2) Q3_TRY_MT(2, 4, 16, 2)
+#undef Q3_TRY_MT
+#undef Q3_TRY_F8
+#undef Q3_TRY
+    Q3_REQUIRE(done, "%s: geometry (tiles %d, k-steps %d, waves %d, epi %d, M %d%s) is not instantiated", who, tiles_per_wg, ksteps_per_wave, waves, epi,
+               M, w_scale ? ", fp8" : "");
+    return q3_check_launch(who);
+}
+
+extern "C" int q3asr_skinny4_gemm(const void* X16, int M, const void* W16, const float* w_scale, int N, int K, int epi, int tiles_per_wg,
+                                  int ksteps_per_wave, int waves, float* slab, void* out, int64_t ldo, void* stream) {
+    return skinny4_launch("skinny4_gemm", X16, nullptr, M, W16, w_scale, N, K, epi, tiles_per_wg, ksteps_per_wave, waves, slab, out, ldo, stream);
+}
+
+extern "C" int q3asr_skinny4_gemm_norm(const float* in_slab, int in_n_slabs, int64_t in_slab_stride, const void* h_in, void* h_out,
+                                       const void* norm_w, float eps, int M, const void* W16, const float* w_scale, int N, int K, int epi,
+                                       int tiles_per_wg, int ksteps_per_wave, int waves, float* slab, void* out, int64_t ldo, void* stream) {
+    FuseNorm f{in_slab, in_n_slabs, (long)in_slab_stride, (const bf16*)h_in, (bf16*)h_out, (const bf16*)norm_w, eps};
+    return skinny4_launch("skinny4_gemm_norm", nullptr, &f, M, W16, w_scale, N, K, epi, tiles_per_wg, ksteps_per_wave, waves, slab, out, ldo, stream);
 }
 
 // ---------------------------------------------------------------------------

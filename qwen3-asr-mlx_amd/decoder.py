@@ -7,6 +7,7 @@ captured into a hipGraph).  bf16 everywhere an MLX op would produce bf16; fp32 a
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from pathlib import Path
 from typing import Optional, Sequence
@@ -114,8 +115,17 @@ class DecodeWorkspace:
         self.geo = {"qkv": ops.gemm_geometry(qkvd, H, fp8=fp8), "o": ops.gemm_geometry(H, qd, fp8=fp8),
                     "down": ops.gemm_geometry(H, I, fp8=fp8), "gu": ops.gemm_geometry(2 * I, H, swiglu=True, fp8=fp8),
                     "head": ops.gemm_geometry(cfg.vocab_size, H, direct=True, fp8=fp8)}
+        # skinny4 geometries (None: no instantiated geometry fits this shape, skinny3 runs)
+        self.geo4 = {"qkv": ops.gemm_geometry4(qkvd, H, 0, fp8, B), "o": ops.gemm_geometry4(H, qd, 0, fp8, B),
+                     "down": ops.gemm_geometry4(H, I, 0, fp8, B), "gu": ops.gemm_geometry4(2 * I, H, 2, fp8, B),
+                     "head": ops.gemm_geometry4(cfg.vocab_size, H, 1, fp8, B)}
+
+        def s4(which, K):
+            g = self.geo4[which]
+            return K // (32 * g[1] * g[2]) if g else 1
         n_slab = max(self.splits["qkv"] * qkvd, self.splits["o"] * H, self.splits["gu"] * 2 * I, self.splits["down"] * H,
-                     self.geo["qkv"][0] * qkvd, self.geo["o"][0] * H, self.geo["down"][0] * H)
+                     self.geo["qkv"][0] * qkvd, self.geo["o"][0] * H, self.geo["down"][0] * H,
+                     s4("qkv", H) * qkvd, s4("o", qd) * H, s4("down", I) * H)
         self.slab = torch.empty((n_slab * B,), dtype=torch.float32, device=device)
         # batch <= 2 runs the residual + RMSNorm inside the consuming GEMM: second slab buffer and residual stream to ping-pong
         self.fused_norm = B <= 2
@@ -146,6 +156,7 @@ class TextDecoder:
         self._plans: dict = {}
         self._ws: dict = {}
         self.decode_impl = "v3"      # "v1": row-major weights, X through LDS, separate rope/swiglu kernels (kept for A/B)
+        self.decode_gemm = os.environ.get("Q3ASR_DECODE_GEMM", "sk4")   # "sk4": skinny4 where a geometry fits; "sk3": skinny3 everywhere (A/B)
         self.fuse_norm = True        # batch <= 2: residual + RMSNorm inside the consuming qkv GEMM (False: separate launches, A/B; tools/ab_batch1.py)
         self.fuse_norm_gu = True     # ... and inside gate/up too
         self._caches: dict = {}
@@ -391,6 +402,12 @@ class TextDecoder:
         self.sample_step(ws, ws.logits, sampling)
 
     def _gemm3(self, ws: DecodeWorkspace, which: str, X16, holder: dict, name: str, N, K, epi, out=None, slab=None) -> int:
+        g4 = ws.geo4[which] if self.decode_gemm == "sk4" else None
+        if g4 is not None:
+            tpw, nks, waves = g4
+            ops.skinny4(X16, ws.B, holder[name + "16"], N, K, epi, tpw, nks, waves,
+                        slab=(slab if slab is not None else ws.slab) if epi == 0 else None, out=out, scale=holder[name + "_s"])
+            return K // (32 * nks * waves)
         S, waves, rt, ksplit = ws.geo[which]
         ops.skinny3(X16, ws.B, holder[name + "16"], N, K, epi, S, waves, slab=(slab if slab is not None else ws.slab) if epi == 0 else None,
                     out=out, rt=rt, ksplit=ksplit, scale=holder[name + "_s"])
@@ -399,6 +416,12 @@ class TextDecoder:
     def _gemm3_norm(self, ws: DecodeWorkspace, which: str, in_slab, s_in, h_in, h_out, norm_w, holder: dict, name: str, N, K, epi,
                     out=None, slab=None) -> int:
         """`_gemm3` with residual + RMSNorm of the operand fused in (q3asr_skinny3_gemm_norm: 4 waves per workgroup)."""
+        g4 = ws.geo4[which] if self.decode_gemm == "sk4" else None
+        if g4 is not None:
+            tpw, nks, waves = g4
+            ops.skinny4_norm(in_slab, s_in, ws.B * K, h_in, h_out, norm_w, self.config.rms_norm_eps, ws.B, holder[name + "16"], N, K, epi,
+                             tpw, nks, waves, slab=slab if epi == 0 else None, out=out, scale=holder[name + "_s"])
+            return K // (32 * nks * waves)
         S, waves, rt, ksplit = ws.geo[which]
         ops.skinny3_norm(in_slab, s_in, ws.B * K, h_in, h_out, norm_w, self.config.rms_norm_eps, ws.B, holder[name + "16"], N, K, epi, S,
                          slab=slab if epi == 0 else None, out=out, rt=rt, ksplit=ksplit, scale=holder[name + "_s"])
@@ -499,7 +522,7 @@ class TextDecoder:
         # (every buffer the captured launches address: K/V blocks AND the attention workspace -- a re-created cache can get
         # its large K/V blocks back from the caching allocator while the small workspace lands elsewhere -- and every switch
         # that changes which launches are recorded)
-        key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.attn_ws.data_ptr(), cache.max_len, self.decode_impl,
+        key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.attn_ws.data_ptr(), cache.max_len, self.decode_impl, self.decode_gemm,
                bool(self.fuse_norm), bool(self.fuse_norm_gu), tuple(sorted(sampling.items())))
         if ws.graph is not None and ws.graph_key == key:
             ws.graph_uses += 1

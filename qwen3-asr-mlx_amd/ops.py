@@ -128,6 +128,19 @@ def skinny3_norm(in_slab, in_n_slabs, in_stride, h_in, h_out, norm_w, eps, M, W1
          N, K, n_splits, epi, 4, rt, 1 if ksplit else 0, ptr(slab), ptr(out), ldo if ldo is not None else N, sp())
 
 
+def skinny4(X16, M, W16, N, K, epi, tpw, nks, waves, slab=None, out=None, ldo=None, scale=None):
+    """q3asr_skinny4_gemm: `waves` waves per `tpw` weight tiles, `nks` k-steps per wave, K / (32 nks waves) slabs."""
+    call("q3asr_skinny4_gemm", ptr(X16), M, ptr(W16), ptr(scale), N, K, epi, tpw, nks, waves, ptr(slab), ptr(out),
+         ldo if ldo is not None else N, sp())
+
+
+def skinny4_norm(in_slab, in_n_slabs, in_stride, h_in, h_out, norm_w, eps, M, W16, N, K, epi, tpw, nks, waves, slab=None, out=None, ldo=None,
+                 scale=None):
+    """skinny4 with the residual add + RMSNorm of its activation operand fused into the prologue (M <= 2)."""
+    call("q3asr_skinny4_gemm_norm", ptr(in_slab), in_n_slabs, in_stride, ptr(h_in), ptr(h_out), ptr(norm_w), eps, M, ptr(W16), ptr(scale),
+         N, K, epi, tpw, nks, waves, ptr(slab), ptr(out), ldo if ldo is not None else N, sp())
+
+
 def pick_splits3(N: int, K: int, waves: int = 4) -> int:
     """Smallest split-K factor that gives >= 256 workgroups (one per CU), K slice >= 128."""
     tiles = (N // 16 + waves - 1) // waves
@@ -157,6 +170,46 @@ _TUNED_F8 = {
     (2048, 6144): (8, 4, 2, True),
     (151936, 2048): (1, 2, 4, True),
 }
+
+
+# skinny4 geometries (tiles per workgroup, k-steps per wave, waves) from tools/micro/sk4.hip: graphs of 28 dependent launches
+# over distinct matrices, batch 32 and batch 1; K / (32 k-steps waves) slabs.  (N, K) -> geometry
+_TUNED4 = {
+    (4096, 2048): (2, 2, 8),             # qkv: 4 slabs, 512 workgroups
+    (2048, 2048): (2, 2, 8),             # o
+    (2048, 6144): (2, 3, 16),            # down: 4 slabs
+    (12288, 2048): (4, 4, 16),           # gate/up (SwiGLU epilogue: one slab)
+    (151936, 2048): (2, 8, 8),           # tied head
+}
+_TUNED4_F8 = {
+    (4096, 2048): (2, 4, 8),
+    (2048, 2048): (2, 2, 8),
+    (2048, 6144): (2, 6, 8),
+    (12288, 2048): (4, 4, 16),
+    (151936, 2048): (4, 8, 8),
+}
+_SK4_BY_EPI = {0: ((2, 2, 8), (2, 4, 8), (2, 6, 8), (2, 3, 16)), 1: ((2, 2, 8), (2, 8, 8), (4, 8, 8)), 2: ((2, 2, 8), (4, 4, 16), (2, 4, 16))}
+
+
+def gemm_geometry4(N: int, K: int, epi: int, fp8: bool = False, M: int = 32):
+    """(tiles_per_wg, ksteps_per_wave, waves) for skinny4 on an (N, K) weight, or None when no instantiated geometry
+    fits (the caller falls back to skinny3).  The choice never depends on M except for the tile count of the 16-wave
+    SwiGLU geometry above 32 rows, which does not change the arithmetic."""
+    def fits(g):
+        tpw, nks, waves = g
+        if g not in _SK4_BY_EPI[epi] or K % (32 * nks * waves) or (N // 16) % tpw or (fp8 and nks % 2):
+            return False
+        return epi == 0 or K == 32 * nks * waves
+    g = (_TUNED4_F8 if fp8 else _TUNED4).get((N, K))
+    if g is None or not fits(g):
+        g = (2, 2, 8)
+        if not fits(g):
+            return None
+    if M > 32 and g[2] * g[0] * 4 > 160:              # partial sums of 4 m-tiles must fit LDS: halve the tiles
+        g = (g[0] // 2, g[1], g[2])
+        if not fits(g):
+            return None
+    return g
 
 
 def gemm_geometry(N: int, K: int, swiglu: bool = False, direct: bool = False, fp8: bool = False):

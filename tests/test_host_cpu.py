@@ -191,6 +191,18 @@ def test_decode_split_choice():
     for n, k in ((1024, 512), (512, 1024), (151936, 2048)):
         s = ops.pick_splits3(n, k)
         assert k % (32 * s) == 0 and k // s >= 128
+    # skinny4: every table entry is an instantiated geometry that fits its shape; the generic rule covers the small config;
+    # the choice is the same for every batch size except the tile count of the 16-wave SwiGLU geometry above 32 rows
+    for fp8, table in ((False, ops._TUNED4), (True, ops._TUNED4_F8)):
+        for (n, k), g in table.items():
+            epi = 2 if n == 12288 else (1 if n == 151936 else 0)
+            assert ops.gemm_geometry4(n, k, epi, fp8, 32) == g and g in ops._SK4_BY_EPI[epi]
+            g64 = ops.gemm_geometry4(n, k, epi, fp8, 64)
+            assert g64[1:] == g[1:] and g64[2] * g64[0] * 4 <= 160
+            assert ops.gemm_geometry4(n, k, epi, fp8, 1) == g
+    assert ops.gemm_geometry4(1024, 512, 0) == (2, 2, 8) and ops.gemm_geometry4(2048, 512, 2) == (2, 2, 8)
+    assert ops.gemm_geometry4(151936, 512, 1) == (2, 2, 8) and ops.gemm_geometry4(512, 1024, 0) == (2, 2, 8)
+    assert ops.gemm_geometry4(1024, 256, 0) is None and ops.gemm_geometry4(48, 512, 0) is None
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

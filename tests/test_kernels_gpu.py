@@ -700,6 +700,48 @@ def test_skinny3_fused_norm_equals_separate_kernels(dev, M, N, K, S_in, S, rt, k
                          out=None if epi == 0 else torch.zeros((N // 2 // 32, 1, 64, 8), dtype=torch.bfloat16, device=dev), rt=rt, ksplit=ksplit, scale=scale)
 
 
+@pytest.mark.parametrize("M,N,K,S_in,geo,epi,fp8", [(1, 4096, 2048, 4, (2, 2, 8), 0, False), (2, 1024, 512, 3, (2, 2, 8), 0, False),
+                                                    (1, 12288, 2048, 4, (4, 4, 16), 2, False), (2, 2048, 512, 6, (2, 2, 8), 2, False),
+                                                    (1, 4096, 2048, 6, (2, 4, 8), 0, True), (2, 12288, 2048, 1, (4, 4, 16), 2, True),
+                                                    (1, 2048, 4096, 2, (2, 4, 8), 0, False)])
+def test_skinny4_fused_norm_equals_separate_kernels(dev, M, N, K, S_in, geo, epi, fp8):
+    """q3asr_skinny4_gemm_norm == q3asr_slab_resnorm_x16 followed by q3asr_skinny4_gemm, bit for bit (residual stream and
+    GEMM output), for 512- and 1024-thread workgroups."""
+    from qwen3_asr_mlx_amd import ops
+    tpw, nks, waves = geo
+    S = K // (32 * nks * waves)
+    in_slab = rnd((S_in, M, K), dev, 174, 0.5, torch.float32)
+    h = rnd((M, K), dev, 175)
+    w = rnd((K,), dev, 176) + 1
+    W = rnd((N, K), dev, 177, 1.5 / math.sqrt(K))
+    if fp8:
+        q8, scale, _ = ops.quantize_fp8_rows(W)
+        wt = ops.to_w16f8(q8)
+    else:
+        wt, scale = ops.to_w16(W), None
+    h1 = torch.empty_like(h)
+    x16 = torch.zeros((K // 32, 1, 64, 8), dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_slab_resnorm_x16", ops.ptr(in_slab), S_in, M * K, ops.ptr(h), ops.ptr(h1), ops.ptr(w), ops.ptr(x16), M, K, 1e-6, ops.sp())
+    h2 = torch.zeros_like(h)
+    if epi == 0:
+        ref = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.skinny4(x16, M, wt, N, K, 0, tpw, nks, waves, slab=ref, scale=scale)
+        got = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.skinny4_norm(in_slab, S_in, M * K, h, h2, w, 1e-6, M, wt, N, K, 0, tpw, nks, waves, slab=got, scale=scale)
+    else:
+        ref = torch.zeros((N // 2 // 32, 1, 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.skinny4(x16, M, wt, N, K, 2, tpw, nks, waves, out=ref, scale=scale)
+        got = torch.zeros_like(ref)
+        ops.skinny4_norm(in_slab, S_in, M * K, h, h2, w, 1e-6, M, wt, N, K, 2, tpw, nks, waves, out=got, scale=scale)
+        ref, got = ops.from_x16(ref, M), ops.from_x16(got, M)
+    assert torch.equal(h2, h1)
+    assert torch.equal(got, ref)
+    with pytest.raises(ValueError):                            # h_in == h_out is refused: neighbours still read h_in
+        ops.skinny4_norm(in_slab, S_in, M * K, h, h, w, 1e-6, M, wt, N, K, epi, tpw, nks, waves,
+                         slab=torch.empty((S, M, N), dtype=torch.float32, device=dev) if epi == 0 else None,
+                         out=None if epi == 0 else torch.zeros((N // 2 // 32, 1, 64, 8), dtype=torch.bfloat16, device=dev), scale=scale)
+
+
 @pytest.mark.parametrize("M,N,S", [(5, 2048, 3), (32, 2048, 8), (33, 512, 1), (2, 4096, 2)])
 def test_slab_resnorm_and_embed_norm_x16(dev, M, N, S):
     import oracle.decoder as od
@@ -853,6 +895,97 @@ def test_skinny3_fp8_weights(dev, M, N, K, S, waves, rt, ksplit, epi):
         r = ref.reshape(M, I // 16, 2, 16)
         g, u = bfr(r[:, :, 0].reshape(M, I)), bfr(r[:, :, 1].reshape(M, I))
         torch.testing.assert_close(ops.from_x16(o16, M).float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=2e-2, rtol=1.6e-2)
+
+
+SK4_CASES = [  # N, K, epi, (tiles per workgroup, k-steps per wave, waves)
+    (4096, 2048, 0, (2, 2, 8)), (2048, 2048, 0, (2, 4, 8)), (2048, 6144, 0, (2, 3, 16)), (2048, 6144, 0, (2, 6, 8)),
+    (1024, 512, 0, (2, 2, 8)), (1024, 512, 1, (2, 2, 8)), (9504, 2048, 1, (2, 8, 8)), (9472, 2048, 1, (4, 8, 8)),
+    (2048, 512, 2, (2, 2, 8)), (12288, 2048, 2, (4, 4, 16)), (12288, 2048, 2, (2, 4, 16)),
+]
+
+
+def _sk4_run(ops, dev, x16, M, wt, scale, N, K, epi, geo):
+    tpw, nks, waves = geo
+    S = K // (32 * nks * waves)
+    if epi == 0:
+        slab = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.skinny4(x16, M, wt, N, K, 0, tpw, nks, waves, slab=slab, scale=scale)
+        return slab
+    if epi == 1:
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        ops.skinny4(x16, M, wt, N, K, 1, tpw, nks, waves, out=out, scale=scale)
+        return out
+    o16 = torch.zeros((N // 64, ops.mt_of(M), 64, 8), dtype=torch.bfloat16, device=dev)
+    ops.skinny4(x16, M, wt, N, K, 2, tpw, nks, waves, out=o16, scale=scale)
+    return o16
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("N,K,epi,geo", SK4_CASES)
+def test_skinny4_matches_reference_and_is_batch_invariant(dev, N, K, epi, geo, fp8):
+    """q3asr_skinny4_gemm against an fp32 product for every instantiated geometry and epilogue, bf16 and fp8 weights, at
+    M = 1 .. 64 (all three m-tile counts, ragged last tile); and the rows of a 64-row launch equal, bit for bit, the same
+    rows computed alone or in a 20-row launch (the k partition depends on the geometry only)."""
+    from qwen3_asr_mlx_amd import ops
+    tpw, nks, waves = geo
+    if fp8 and nks % 2:
+        pytest.skip("fp8 fragments come in pairs of k steps")
+    X = rnd((64, K), dev, 160)
+    W = rnd((N, K), dev, 161, (2.0 if epi == 2 else 1.0) / math.sqrt(K))
+    if fp8:
+        q8, scale, w_eff = ops.quantize_fp8_rows(W)
+        wt = ops.to_w16f8(q8)
+    else:
+        scale, w_eff, wt = None, W, ops.to_w16(W)
+    ref_all = X.float().cpu() @ w_eff.float().cpu().T
+    results = {}
+    for M in (64, 33, 32, 20, 16, 7, 1):
+        if M > 32 and waves * tpw * 4 > 160:
+            continue                                      # 4 m-tiles of partial sums do not fit LDS: the decoder halves the tiles
+        got = _sk4_run(ops, dev, ops.to_x16(X[:M].contiguous()), M, wt, scale, N, K, epi, geo)
+        ref = ref_all[:M]
+        if epi == 0:
+            torch.testing.assert_close(got.sum(0).cpu(), ref, atol=2e-3, rtol=1e-3)
+            results[M] = got
+        elif epi == 1:
+            torch.testing.assert_close(got.float().cpu(), bfr(ref), atol=2e-2, rtol=8e-3)
+            results[M] = got
+        else:
+            I = N // 2
+            r = ref.reshape(M, I // 16, 2, 16)
+            g, u = bfr(r[:, :, 0].reshape(M, I)), bfr(r[:, :, 1].reshape(M, I))
+            act = ops.from_x16(got, M)
+            torch.testing.assert_close(act.float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=2e-2, rtol=1.6e-2)
+            results[M] = act
+    Ms = sorted(results)
+    big = results[Ms[-1]]
+    for M in Ms[:-1]:
+        if epi == 0:
+            assert torch.equal(results[M], big[:, :M]), f"rows differ between M={M} and M={Ms[-1]}"
+        else:
+            assert torch.equal(results[M], big[:M]), f"rows differ between M={M} and M={Ms[-1]}"
+
+
+def test_skinny4_tile_count_does_not_change_bits(dev):
+    """(4, 4, 16) and (2, 4, 16) -- what the decoder switches between at 32 / 33 rows -- give identical SwiGLU outputs."""
+    from qwen3_asr_mlx_amd import ops
+    N, K, M = 12288, 2048, 32
+    X = rnd((M, K), dev, 162)
+    W = rnd((N, K), dev, 163, 2.0 / math.sqrt(K))
+    a = _sk4_run(ops, dev, ops.to_x16(X), M, ops.to_w16(W), None, N, K, 2, (4, 4, 16))
+    b = _sk4_run(ops, dev, ops.to_x16(X), M, ops.to_w16(W), None, N, K, 2, (2, 4, 16))
+    assert torch.equal(a, b)
+
+
+def test_skinny4_rejects_uninstantiated_geometry(dev):
+    from qwen3_asr_mlx_amd import _lib, ops
+    X = rnd((4, 512), dev, 164)
+    W = rnd((64, 512), dev, 165)
+    slab = torch.empty((1, 4, 64), dtype=torch.float32, device=dev)
+    with pytest.raises((_lib.Q3AsrError, ValueError), match="not instantiated"):
+        ops.skinny4(ops.to_x16(X), 4, ops.to_w16(W), 64, 512, 0, 1, 2, 8, slab=slab)
+    with pytest.raises((_lib.Q3AsrError, ValueError), match="multiple"):
+        ops.skinny4(ops.to_x16(X), 4, ops.to_w16(W), 64, 512, 0, 2, 3, 16, slab=slab)
 
 
 @pytest.mark.parametrize("M,S", [(32, 2), (32, 4), (32, 8), (7, 3), (64, 8), (1, 4)])
