@@ -776,7 +776,8 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_o
 // writes and for the transposing reads (same image as the prefill kernel, attn.hip)
 __device__ __forceinline__ int adm_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-template <bool MFMA>
+// NT (MFMA path): the cached keys / values are read with non-temporal loads (a cache that is streamed once per step).
+template <bool MFMA, bool NT = false>
 __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
                                                                 const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
                                                                 const float* __restrict__ inv_freq, float eps,
@@ -840,14 +841,15 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     const int li = i;
     bf16x8 kR[2][4];
     u32x4 vR[8];
+#define ADM_LD(P) (NT ? __builtin_nontemporal_load(P) : *(P))
 #define ADM_LOAD(KR, VR, TB)                                                                                    \
     _Pragma("unroll") for (int k4 = 0; k4 < 2; ++k4) {                                                      \
         const long kr_ = (long)min((TB) + 16 * k4 + li, t_last) * 128 + 8 * g;                              \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) KR[k4][ks] = *reinterpret_cast<const bf16x8*>(Kb + kr_ + 32 * ks); \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) KR[k4][ks] = ADM_LD(reinterpret_cast<const bf16x8*>(Kb + kr_ + 32 * ks)); \
     }                                                                                                       \
     _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                      \
         const int c_ = lane + 64 * it;                                                                      \
-        VR[it] = *reinterpret_cast<const u32x4*>(Vb + (long)min((TB) + (c_ >> 4), t_last) * 128 + 8 * (c_ & 15)); \
+        VR[it] = ADM_LD(reinterpret_cast<const u32x4*>(Vb + (long)min((TB) + (c_ >> 4), t_last) * 128 + 8 * (c_ & 15))); \
         }
     if constexpr (MFMA) {
         if (t0 + 32 * wave < min(L, t0 + ADF_CHUNK)) { ADM_LOAD(kR, vR, t0 + 32 * wave) }
@@ -1107,6 +1109,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
 #undef ADM_SOFTMAX_PV
 #undef ADM_STAGE_QK
 #undef ADM_LOAD
+#undef ADM_LD
     }
 #undef Q3_LOAD_BATCH
     if (n_active == 1) return;                                        // uniform
@@ -1196,15 +1199,29 @@ extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_
     // MFMA formulation by default; Q3ASR_ATTN=valu keeps the lane-group dot-product kernel (A/B, cross-check in the tests)
     static const bool valu = [] { const char* e = getenv("Q3ASR_ATTN"); return e && e[0] == 'v'; }();
     if (valu || g_attn_force_valu) {
-        hipLaunchKernelGGL(attn_decode_fused_kernel<false>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+        hipLaunchKernelGGL((attn_decode_fused_kernel<false, false>), dim3(nkv, B, (nc + G - 1) / G), dim3(512), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
                            (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
                            nkv, Lmax, scale, part, counters, nc, G);
     } else {
         static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192); attr = true; }
-        hipLaunchKernelGGL(attn_decode_fused_kernel<true>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
-                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
-                           nkv, Lmax, scale, part, counters, nc, G);
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+            (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+            attr = true;
+        }
+        // K/V larger than the caches can keep from one step to the next are streamed with non-temporal loads (batch 32, 512-token
+        // capacity: 67 MB per layer; 252 -> 250 ms per request); a small cache stays resident in L2 / Infinity Cache between steps
+        // and default-policy loads are faster there (batch 1: 162.4 vs 167.2 ms).  Q3ASR_ATTN_NT=0/1 forces either.
+        static const int nt_forced = [] { const char* e = getenv("Q3ASR_ATTN_NT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        const bool nt = nt_forced >= 0 ? nt_forced == 1 : (int64_t)B * nkv * Lmax * 512 > (16LL << 20);
+        if (nt)
+            hipLaunchKernelGGL((attn_decode_fused_kernel<true, true>), dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+                               (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
+                               nkv, Lmax, scale, part, counters, nc, G);
+        else
+            hipLaunchKernelGGL((attn_decode_fused_kernel<true, false>), dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+                               (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
+                               nkv, Lmax, scale, part, counters, nc, G);
     }
     return q3_check_launch("attn_decode_fused");
 }

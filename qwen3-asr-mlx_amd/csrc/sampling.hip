@@ -172,6 +172,9 @@ __device__ __forceinline__ void penalty_setup(const SampleParams& p, const bf16*
 
 // bookkeeping (generate.py:286-313): EOS is recorded, then the sequence stops
 __device__ __forceinline__ void commit_token(const SampleParams& p, int b, int n, int token) {
+    // A row of NaN logits (a diverged model, a corrupt checkpoint) has no maximum and no sampled index: the sentinel must not
+    // reach the embedding gather of the next step as a row number.  Such a row emits token 0 (results are meaningless either way).
+    if (token < 0 || token >= p.V) token = 0;
     if (!p.finished[b]) {
         if (n < p.max_out) p.out_tokens[(long)b * p.max_out + n] = token;
         const int n1 = n + 1;

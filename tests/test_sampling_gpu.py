@@ -24,6 +24,18 @@ def test_greedy_lowest_index_on_ties_and_big_vocab(dev):
     assert sample(x, temperature=0.0) == int(torch.argmax(x))
 
 
+def test_nan_logits_never_yield_an_out_of_range_token(dev):
+    """A row without a maximum (all NaN) must not hand the argmax sentinel to the next step's embedding gather."""
+    from qwen3_asr_mlx_amd import sample
+    x = torch.full((1, 4096), float("nan"))
+    assert 0 <= sample(x, temperature=0.0) < 4096
+    for kw in (dict(temperature=0.7, top_p=0.9), dict(temperature=1.0, top_k=5), dict(temperature=1.0)):
+        assert 0 <= sample(x, seed=3, **kw) < 4096
+    x = torch.randn(1, 4096)
+    x[0, 100:200] = float("nan")                       # NaNs beside finite logits: still a valid index
+    assert 0 <= sample(x, temperature=0.0) < 4096
+
+
 def test_temperature_sampling_is_stochastic(dev):
     from qwen3_asr_mlx_amd import sample
     logits = torch.ones(1, 512)

@@ -42,6 +42,10 @@ for step in "$@"; do
                   python3 $R/tools/mfma_util.py $(find $O/${TAG}_mfma -name '*counter_collection.csv') $(find $O/${TAG}_mfma -name '*kernel_trace.csv') $O/${TAG}_mfma_util.json > $O/${TAG}_mfma_print.txt 2>&1; tail -16 $O/${TAG}_mfma_print.txt ;;
     stats)        prof stats decode,encoder,prefill,step --kernel-trace --stats
                   find $O/${TAG}_stats -name '*kernel_stats.csv' -exec head -30 {} \; ;;
+    trace_graph)  rm -rf $O/${TAG}_trace_graph; run 420 $O/${TAG}_trace_graph.log rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_graph -- python3 $R/tools/pmc_probe.py graph4
+                  python3 $R/tools/agg_trace.py $(find $O/${TAG}_trace_graph -name '*kernel_trace.csv') 24 > $O/${TAG}_trace_graph.txt; cat $O/${TAG}_trace_graph.txt; find $O/${TAG}_trace_graph -name '*.csv' -size +20M -delete ;;
+    trace_graph1) rm -rf $O/${TAG}_trace_graph1; run 420 $O/${TAG}_trace_graph1.log rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_graph1 -- python3 $R/tools/pmc_probe.py graph4 --batch 1
+                  python3 $R/tools/agg_trace.py $(find $O/${TAG}_trace_graph1 -name '*kernel_trace.csv') 24 > $O/${TAG}_trace_graph1.txt; cat $O/${TAG}_trace_graph1.txt; find $O/${TAG}_trace_graph1 -name '*.csv' -size +20M -delete ;;
     probe_batch1) prof probe_batch1 batch1 --pmc FETCH_SIZE --kernel-trace ;;
     probe_graph)  prof probe_graph graph --pmc FETCH_SIZE --kernel-trace ;;
     probe_graph4) prof probe_graph4 graph4 --pmc FETCH_SIZE --kernel-trace ;;

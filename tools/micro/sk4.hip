@@ -267,6 +267,64 @@ __global__ __launch_bounds__(64 * WAVES) void sk4_kernel(const bf16* __restrict_
     }
 }
 
+// sk5: sk4 (bf16, slab epilogue) with the m-tiles taken in passes of MC over the same weight registers (X per pass)
+template <int MT, int TPW, int NKS, int WAVES, int MC>
+__global__ __launch_bounds__(64 * WAVES) void sk5_kernel(const bf16* __restrict__ X16, const bf16* __restrict__ W16, int M, int N, int K,
+                                                         float* __restrict__ slab) {
+    extern __shared__ f32x4 red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t0 = blockIdx.x * TPW;
+    const int ks0 = (blockIdx.y * WAVES + wave) * NKS;
+    const long tile_stride = (long)(K >> 5) * 512;
+    bf16x8 xf[NKS][MC], w[NKS][TPW];
+    const bf16* xp = X16 + (long)ks0 * MT * 512 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < NKS; ++i)
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) xf[i][mc] = *reinterpret_cast<const bf16x8*>(xp + ((long)i * MT + mc) * 512);
+#pragma unroll
+    for (int i = 0; i < NKS; ++i)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+            w[i][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(W16 + (long)(t0 + t) * tile_stride + (long)(ks0 + i) * 512 + lane * 8));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m0 = 0; m0 < MT; m0 += MC) {
+        if (m0 > 0) {
+#pragma unroll
+            for (int i = 0; i < NKS; ++i)
+#pragma unroll
+                for (int mc = 0; mc < MC; ++mc) xf[i][mc] = *reinterpret_cast<const bf16x8*>(xp + ((long)i * MT + m0 + mc) * 512);
+        }
+        f32x4 acc[TPW][MC];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc) acc[t][mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NKS; ++i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int mc = 0; mc < MC; ++mc) acc[t][mc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][t], xf[i][mc], acc[t][mc], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int mc = 0; mc < MC; ++mc) red[((wave * TPW + t) * MT + m0 + mc) * 64 + lane] = acc[t][mc];
+    }
+    __syncthreads();
+    const int g = lane >> 4, li = lane & 15;
+    for (int c = wave; c < TPW * MT; c += WAVES) {
+        const int t = c / MT, mt = c % MT;
+        f32x4 a = red[((0 * TPW + t) * MT + mt) * 64 + lane];
+#pragma unroll
+        for (int ww = 1; ww < WAVES; ++ww) a += red[((ww * TPW + t) * MT + mt) * 64 + lane];
+        const int m = 16 * mt + li;
+        if (m >= M) continue;
+        *reinterpret_cast<f32x4*>(slab + ((long)blockIdx.y * M + m) * N + 16 * (t0 + t) + 4 * g) = a;
+    }
+}
+
 __global__ void ref8_kernel(const bf16* X16, const unsigned char* W8, int M, int N, int K, int MT, float* C) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)M * N) return;
@@ -412,6 +470,26 @@ static void run_sk4(const Shape& s) {
     else run_sk4_<MT, TPW, NKS, EPI, WAVES, false>(s);
 }
 
+template <int MT, int TPW, int NKS, int WAVES, int MC>
+static void run_sk5(const Shape& s) {
+    if (F8_) return;
+    const int n_tiles = s.N / 16;
+    const int S = s.K / 32 / (WAVES * NKS);
+    if (S < 1 || S * WAVES * NKS * 32 != s.K || n_tiles % TPW || s.epi != 0) return;
+    dim3 grid(n_tiles / TPW, S), blk(64 * WAVES);
+    const size_t lds = (size_t)WAVES * TPW * MT * 64 * 16;
+    if (lds > 160 * 1024) return;
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)sk5_kernel<MT, TPW, NKS, WAVES, MC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    auto go = [&](bf16* W) { hipLaunchKernelGGL((sk5_kernel<MT, TPW, NKS, WAVES, MC>), grid, blk, lds, st, X, W, M_, s.N, s.K, SLAB); };
+    go(Ws[0]); CK(hipStreamSynchronize(st));
+    const double err = check(s, S);
+    const float us = time_case(go);
+    printf("%-5s sk5 TPW=%d NKS=%d WAVES=%2d MC=%d S=%d grid=%5dx%-2d  %7.2f us  %5.2f TB/s  err %.1e\n", s.name, TPW, NKS, WAVES, MC, S,
+           grid.x, grid.y, us, wbytes(s) / us * 1e-6, err);
+    fflush(stdout);
+}
+
 template <int MT>
 static void sweep(const char* only) {
     const Shape shapes[] = {{"qkv", 4096, 2048, 0}, {"o", 2048, 2048, 0}, {"gu", 12288, 2048, 2}, {"down", 2048, 6144, 0}, {"head", 151936, 2048, 1}};
@@ -457,6 +535,16 @@ static void sweep(const char* only) {
             run_sk4<MT, 2, 2, 0, 16>(s);     // S=6
             run_sk4<MT, 4, 2, 0, 16>(s);     // S=6
             run_sk4<MT, 1, 2, 0, 16>(s);     // S=6
+            if constexpr (MT == 2) {
+                run_sk5<MT, 1, 24, 8, 1>(s);     // complete sums: 128 workgroups of 8 waves
+                run_sk5<MT, 1, 12, 16, 1>(s);    // complete sums: 128 workgroups of 16 waves
+                run_sk5<MT, 1, 12, 16, 2>(s);
+                run_sk5<MT, 1, 12, 8, 1>(s);     // S=2
+                run_sk5<MT, 1, 12, 8, 2>(s);     // S=2
+            } else {
+                run_sk5<MT, 1, 24, 8, 1>(s);
+                run_sk5<MT, 1, 12, 16, 1>(s);
+            }
         } else {
             run_sk3<MT, 0, 2>(s, 4, 4, 1);
             run_sk3<MT, 0, 1>(s, 8, 2, 0);
@@ -470,6 +558,9 @@ static void sweep(const char* only) {
             run_sk4<MT, 2, 1, 0, 16>(s);     // S=4 (bf16 only)
             run_sk4<MT, 4, 1, 0, 16>(s);     // S=4 (bf16 only)
             run_sk4<MT, 2, 1, 0, 8>(s);      // S=8 (bf16 only)
+            run_sk4<MT, 1, 8, 0, 8>(s);      // complete sums
+            run_sk4<MT, 1, 4, 0, 16>(s);     // complete sums
+            run_sk4<MT, 2, 8, 0, 8>(s);      // complete sums
         }
         for (bf16* p : Ws) CK(hipFree(p));
         Ws.clear();
