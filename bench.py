@@ -433,7 +433,7 @@ def main() -> None:
                     "(encoder 374.1 GFLOP and prefill 1,170 GFLOP per 30 s clip, decode 3.441 GB weights + B*L*114,688 B KV per token)",
         }
         log("stages: " + ", ".join(f"{k}={v:.1f}" for k, v in line["stages"].items() if k.endswith("_ms")))
-        # ---- roofline of the dominant kernel (decode weight streaming: skinny3_kernel).  HIP events on the
+        # ---- roofline of the dominant kernel (decode weight streaming: skinny4_kernel; skinny3_kernel where no skinny4 geometry fits).  HIP events on the
         # launch stream around R back-to-back "GEMM-only" decode steps: exactly the 113 weight-streaming
         # launches of a step (4 per layer over all 28 layers' distinct weights, so 3.4 GB per step and no
         # cache reuse between launches, + the tied head), same operands and split factors as the timed region.
@@ -456,19 +456,20 @@ def main() -> None:
         total_bytes = sum(per_launch) * R
         avg_ms = ms.value / launches
         achieved = total_bytes / (ms.value * 1e-3) / 1e9
-        log(f"roofline leg: {launches} skinny3 launches in {ms.value:.2f} ms")
+        log(f"roofline leg: {launches} decode GEMM launches in {ms.value:.2f} ms")
         # PMC traffic: only a figure collected on THIS build of the library (tools/pmc_probe.py stamps the summary with the
         # sha-256 of libq3asr_hip.so); a summary from any other build is refused and `traffic` is null.
         traffic, traffic_from = None, "no PMC summary for this build of libq3asr_hip.so"
         lib_sha = lib_sha16()
         for pmc in sorted((ROOT / "profiles").glob("r*_pmc_summary.json"), reverse=True):
             d_ = json.loads(pmc.read_text())
-            if d_.get("lib_sha16") == lib_sha and d_.get("skinny3_hbm_bytes_per_launch"):
-                traffic, traffic_from = d_["skinny3_hbm_bytes_per_launch"], f"profiles/{pmc.name} (lib sha16 {lib_sha})"
+            per = d_.get("decode_gemm_hbm_bytes_per_launch") or d_.get("skinny3_hbm_bytes_per_launch")
+            if d_.get("lib_sha16") == lib_sha and per:
+                traffic, traffic_from = per, f"profiles/{pmc.name} (lib sha16 {lib_sha})"
                 break
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
-                            "kernel": "skinny3_kernel (decode weight streaming, all shapes of one step)",
+                            "kernel": "skinny4_kernel (decode weight streaming, all shapes of one step)",
                             "launches_measured": launches, "avg_launch_us": 1e3 * avg_ms,
                             "bytes_per_launch": sum(per_launch) / len(per_launch)}
         if not args.no_cpu_baseline and args.weights == "bf16":

@@ -30,14 +30,14 @@ for key in sorted(fetch, key=lambda k: -sum(fetch[k])):
     rows.append({"kernel": key[0], "grid_threads": key[1], "wg": key[2], "dispatches": len(f),
                  "FETCH_SIZE_KB_avg": round(sum(f) / len(f), 1), "hbm_read_MB_corrected_x2": round(2 * sum(f) / len(f) * 1024 / 1e6, 2),
                  "WRITE_SIZE_KB_avg": round(sum(w) / len(w), 1), "hbm_write_MB": round(sum(w) / len(w) * 1024 / 1e6, 2)})
-sk = [r for r in rows if "skinny3_kernel" in r["kernel"]]
+sk = [r for r in rows if "skinny4_kernel" in r["kernel"] or "skinny3_kernel" in r["kernel"]]
 n = sum(r["dispatches"] for r in sk)
 meta = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else {}
 out = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/pmc_probe.py " + ",".join(meta.get("ran", ["?"])) +
                   "  (second pass with --pmc WRITE_SIZE)",
        "lib_sha16": meta.get("lib_sha16"), "probe": meta,
        "correction": "gfx950: read bytes = 2 * FETCH_SIZE * 1024; write bytes = WRITE_SIZE * 1024",
-       "skinny3_hbm_bytes_per_launch": int(sum((r["hbm_read_MB_corrected_x2"] + r["hbm_write_MB"]) * 1e6 * r["dispatches"] for r in sk) / max(n, 1)),
+       "decode_gemm_hbm_bytes_per_launch": int(sum((r["hbm_read_MB_corrected_x2"] + r["hbm_write_MB"]) * 1e6 * r["dispatches"] for r in sk) / max(n, 1)),
        "kernels": rows[:40]}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))

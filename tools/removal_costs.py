@@ -32,9 +32,9 @@ real_call = ops.call
 
 
 def call(name, *a):
-    if name in skip or (name == "q3asr_skinny3_gemm" and ("gemm:%d" % a[4]) in skip):      # a[4] = N
+    if name in skip or (name in ("q3asr_skinny3_gemm", "q3asr_skinny4_gemm") and ("gemm:%d" % a[4]) in skip):      # a[4] = N
         return
-    if name == "q3asr_skinny3_gemm_norm" and ("gemm:%d" % a[10]) in skip:                  # fused small-batch form: a[10] = N
+    if name in ("q3asr_skinny3_gemm_norm", "q3asr_skinny4_gemm_norm") and ("gemm:%d" % a[10]) in skip:                  # fused small-batch form: a[10] = N
         return
     return real_call(name, *a)
 

@@ -15,7 +15,7 @@ i = 0
 while i < len(seq):
     if seq[i][2].startswith("_Z21embed_norm_x16"):
         j = i
-        while j < len(seq) and (seq[j][2].startswith(("_Z21embed_norm", "void skinny3", "_Z24attn_decode", "_Z23slab_resnorm", "sample_"))):
+        while j < len(seq) and (seq[j][2].startswith(("_Z21embed_norm", "void skinny3", "void skinny4", "_Z24attn_decode", "_Z23slab_resnorm", "sample_"))):
             j += 1
         out.append(f"  [decode graph replays: {j-i} kernels, {(seq[j-1][1]-seq[i][0])/1e6:.2f} ms]")
         i = j
