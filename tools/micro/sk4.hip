@@ -325,6 +325,76 @@ __global__ __launch_bounds__(64 * WAVES) void sk5_kernel(const bf16* __restrict_
     }
 }
 
+// sk6: persistent sk4 for the tied head (bf16, EPI 1): grid.x workgroups loop over tile groups t = blockIdx.x, + gridDim.x, ...;
+// a wave's X fragments (its k-steps never change) stay in registers for the whole launch; the next group's weights are
+// requested before this group's partial sums are reduced.
+template <int MT, int TPW, int NKS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sk6_kernel(const bf16* __restrict__ X16, const bf16* __restrict__ W16, int M, int N, int K,
+                                                         bf16* __restrict__ out, long ldo) {
+    extern __shared__ f32x4 red[];                          // [2][WAVES][TPW][MT][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_groups = (N >> 4) / TPW;
+    const int ks0 = wave * NKS;
+    const long tile_stride = (long)(K >> 5) * 512;
+    bf16x8 xf[NKS][MT], wA[NKS][TPW], wB[NKS][TPW];
+    const bf16* xp = X16 + (long)ks0 * MT * 512 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < NKS; ++i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[i][mt] = *reinterpret_cast<const bf16x8*>(xp + ((long)i * MT + mt) * 512);
+    auto loadw = [&](bf16x8 (&w)[NKS][TPW], int grp) {
+        const bf16* wp = W16 + ((long)grp * TPW * (K >> 5) + ks0) * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NKS; ++i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) w[i][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ((long)t * (K >> 5) + i) * 512));
+    };
+    const int g = lane >> 4, li = lane & 15;
+    auto body = [&](const bf16x8 (&w)[NKS][TPW], int grp, int buf) {
+        f32x4 acc[TPW][MT];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NKS; ++i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][t], xf[i][mt], acc[t][mt], 0, 0, 0);
+        f32x4* r = red + buf * WAVES * TPW * MT * 64;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) r[((wave * TPW + t) * MT + mt) * 64 + lane] = acc[t][mt];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int c = wave; c < TPW * MT; c += WAVES) {
+            const int t = c / MT, mt = c % MT;
+            f32x4 a = r[(t * MT + mt) * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < WAVES; ++ww) a += r[((ww * TPW + t) * MT + mt) * 64 + lane];
+            const int m = 16 * mt + li;
+            if (m >= M) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(a[e]);
+            *reinterpret_cast<bf16x4*>(out + (long)m * ldo + 16 * (grp * TPW + t) + 4 * g) = o;
+        }
+    };
+    int grp = blockIdx.x;
+    if (grp < n_groups) loadw(wA, grp);
+    for (; grp < n_groups; grp += 2 * gridDim.x) {
+        if (grp + (int)gridDim.x < n_groups) loadw(wB, grp + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        body(wA, grp, 0);
+        if (grp + 2 * (int)gridDim.x < n_groups) loadw(wA, grp + 2 * gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp + (int)gridDim.x < n_groups) body(wB, grp + gridDim.x, 1);
+    }
+}
+
 __global__ void ref8_kernel(const bf16* X16, const unsigned char* W8, int M, int N, int K, int MT, float* C) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)M * N) return;
@@ -490,6 +560,22 @@ static void run_sk5(const Shape& s) {
     fflush(stdout);
 }
 
+template <int MT, int TPW, int NKS, int WAVES>
+static void run_sk6(const Shape& s, int nwg) {
+    if (F8_ || s.epi != 1 || WAVES * NKS * 32 != s.K || (s.N / 16) % TPW) return;
+    dim3 grid(nwg), blk(64 * WAVES);
+    const size_t lds = (size_t)2 * WAVES * TPW * MT * 64 * 16;
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)sk6_kernel<MT, TPW, NKS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    auto go = [&](bf16* W) { hipLaunchKernelGGL((sk6_kernel<MT, TPW, NKS, WAVES>), grid, blk, lds, st, X, W, M_, s.N, s.K, OUT, (long)s.N); };
+    CK(hipMemsetAsync(OUT, 0, (size_t)M_ * s.N * 2, st));
+    go(Ws[0]); CK(hipStreamSynchronize(st));
+    const double err = check(s, 1);
+    const float us = time_case(go);
+    printf("%-5s sk6 TPW=%d NKS=%d WAVES=%2d persistent grid=%5d  %7.2f us  %5.2f TB/s  err %.1e\n", s.name, TPW, NKS, WAVES, nwg, us, wbytes(s) / us * 1e-6, err);
+    fflush(stdout);
+}
+
 template <int MT>
 static void sweep(const char* only) {
     const Shape shapes[] = {{"qkv", 4096, 2048, 0}, {"o", 2048, 2048, 0}, {"gu", 12288, 2048, 2}, {"down", 2048, 6144, 0}, {"head", 151936, 2048, 1}};
@@ -522,6 +608,12 @@ static void sweep(const char* only) {
             run_sk4<MT, 4, 4, 1, 16>(s);
             run_sk4<MT, 8, 4, 1, 16>(s);
             run_sk4<MT, 8, 8, 1, 8>(s);
+            for (int nwg : {256, 512, 768, 1024}) {
+                run_sk6<MT, 2, 8, 8>(s, nwg);
+                run_sk6<MT, 2, 4, 16>(s, nwg);
+            }
+            run_sk6<MT, 4, 4, 16>(s, 256);
+            run_sk6<MT, 4, 4, 16>(s, 512);
         } else if (s.K == 6144) {
             run_sk3<MT, 0, 1>(s, 8, 4, 1);
             run_sk4<MT, 2, 8, 0, 8>(s);      // S=3
