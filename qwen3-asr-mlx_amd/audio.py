@@ -167,16 +167,38 @@ def get_frontend(device=None, sample_rate: int = SAMPLE_RATE, f_min: float = F_M
     return fe
 
 
+_staging = threading.local()     # per thread (= per lane): a pinned host buffer that outlives the call, and the event of its last copy
+
+
 def pack_audio(batch: Sequence[np.ndarray], device):
-    """Host list of 1-D float32 arrays -> (padded device tensor [B][Lmax], lens device, lens host)."""
+    """Host list of 1-D float32 arrays -> (padded device tensor [B][Lmax], lens device, lens host).
+    The rows are staged in a pinned buffer kept per thread (allocating 61 MB of pinned memory per 32 x 30 s request cost
+    4-25 ms of a 250 ms request); the buffer is reused only after the copy that last read it has completed."""
     import torch
     lens = [int(len(a)) for a in batch]
     lmax = max(lens)
-    host = torch.zeros((len(batch), lmax), dtype=torch.float32, pin_memory=torch.cuda.is_available())
+    n = len(batch) * lmax
+    if not torch.cuda.is_available():
+        host = torch.zeros((len(batch), lmax), dtype=torch.float32)
+        for i, a in enumerate(batch):
+            host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        return host.to(device), torch.tensor(lens, dtype=torch.int32).to(device), lens
+    st = getattr(_staging, "buf", None)
+    if st is None or st[0].numel() < n:
+        st = _staging.buf = (torch.empty((max(n, 1 << 20),), dtype=torch.float32, pin_memory=True), None)
+    flat, ev = st
+    if ev is not None:
+        ev.synchronize()                                   # the previous request's H2D copy has read the buffer
+    host = flat[:n].view(len(batch), lmax)
     for i, a in enumerate(batch):
         host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        if lens[i] < lmax:
+            host[i, lens[i]:] = 0.0
     dev = host.to(device, non_blocking=True)
     lens_dev = torch.tensor(lens, dtype=torch.int32).to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev.device))
+    _staging.buf = (flat, ev)
     return dev, lens_dev, lens
 
 
