@@ -120,6 +120,10 @@ class DecodeWorkspace:
                      "down": ops.gemm_geometry4(H, I, 0, fp8, B), "gu": ops.gemm_geometry4(2 * I, H, 2, fp8, B),
                      "head": ops.gemm_geometry4(cfg.vocab_size, H, 1, fp8, B)}
 
+        for item in filter(None, os.environ.get("Q3ASR_GEO4", "").split(";")):     # tuning knob: "qkv=2,4,8;down=2,6,8"
+            which, g = item.split("=")
+            self.geo4[which] = tuple(int(v) for v in g.split(","))
+
         def s4(which, K):
             g = self.geo4[which]
             return K // (32 * g[1] * g[2]) if g else 1

@@ -175,7 +175,8 @@ _TUNED_F8 = {
 # skinny4 geometries (tiles per workgroup, k-steps per wave, waves) from tools/micro/sk4.hip: graphs of 28 dependent launches
 # over distinct matrices, batch 32 and batch 1; K / (32 k-steps waves) slabs.  (N, K) -> geometry
 _TUNED4 = {
-    (4096, 2048): (2, 2, 8),             # qkv: 4 slabs, 512 workgroups
+    (4096, 2048): (2, 4, 8),             # qkv: 2 slabs (isolated: (2,2,8) with 4 slabs is 0.3 us faster; inside the captured step the
+                                         # attention prologue then adds 4 slabs instead of 2: 251.5 -> 249.1 ms per request, batch 1 162.5 -> 160.8)
     (2048, 2048): (2, 2, 8),             # o
     (2048, 6144): (2, 3, 16),            # down: 4 slabs
     (12288, 2048): (4, 4, 16),           # gate/up (SwiGLU epilogue: one slab)
