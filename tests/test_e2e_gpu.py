@@ -591,6 +591,23 @@ def test_log_mel_public_function(dev):
         q.log_mel_spectrogram(signal("noise", 16000), n_fft=512)
 
 
+def test_pack_audio_reuses_its_pinned_buffer_only_after_the_copy(dev):
+    """Back-to-back packs on one thread share one pinned staging buffer: every returned device tensor holds its own
+    request (the second pack waits for the first copy's event before overwriting the buffer), shrinking and growing
+    requests included, padding zeroed."""
+    import qwen3_asr_mlx_amd as q
+    reqs = [[signal("noise", 48000, seed=s) for s in range(8)], [signal("speechlike", 16000 + 37 * s, seed=40 + s) for s in range(3)],
+            [signal("noise", 480000, seed=50 + s) for s in range(4)], [signal("tone", 1600, seed=9)]]
+    packed = [q.audio.pack_audio(r, dev) for r in reqs]              # no synchronisation in between
+    torch.cuda.synchronize()
+    for r, (d, lens_dev, lens) in zip(reqs, packed):
+        assert lens == [len(a) for a in r] and lens_dev.tolist() == lens
+        host = d.cpu().numpy()
+        for i, a in enumerate(r):
+            assert np.array_equal(host[i, : len(a)], a.astype(np.float32))
+            assert not host[i, len(a):].any()
+
+
 def test_generate_reference_signature(dev, small):
     """generate()/prepare_inputs()/sample() keep the reference call shapes (test_generate.py:201-242)."""
     import oracle

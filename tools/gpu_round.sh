@@ -31,7 +31,7 @@ for step in "$@"; do
     bench)        run 600 $O/${TAG}_bench.err python3 $R/bench.py --steps 20 --warmup 3 ; grep '^{' $O/${TAG}_bench.err > $O/${TAG}_bench.json; grep -v '^{' $O/${TAG}_bench.err | tail -25 ;;
     benchq)       run 400 $O/${TAG}_benchq.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchq.err > $O/${TAG}_benchq.json; grep -v '^{' $O/${TAG}_benchq.err | tail -12 ;;
     benchq_sk3)   Q3ASR_DECODE_GEMM=sk3 run 400 $O/${TAG}_benchq_sk3.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchq_sk3.err > $O/${TAG}_benchq_sk3.json; grep -v '^{' $O/${TAG}_benchq_sk3.err | tail -12 ;;
-    benchq_geo)   for g in "qkv=2,4,8" "down=2,6,8" "qkv=2,4,8;down=2,6,8"; do
+    benchq_geo)   for g in ${Q3ASR_GEO_LIST:-"o=2,4,8" "qkv=2,2,8"}; do
                       echo "Q3ASR_GEO4=$g" | tee -a $O/${TAG}_steps.log
                       Q3ASR_GEO4="$g" run 400 $O/${TAG}_benchq_geo.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs
                       grep -E "timed step|batch-1|stages" $O/${TAG}_benchq_geo.err | tail -3
