@@ -363,9 +363,10 @@ extern "C" int q3asr_skinny3_gemm_norm(const float* in_slab, int in_n_slabs, int
 //     slab_s[m][n] = ((p_{s,0} + p_{s,1}) + ...) + p_{s,WAVES-1},  p = one k-ascending MFMA chain over NKS steps,
 // a function of (NKS, WAVES, S) only: the batch size (MT) and TPW never change a bit.  M > 32 runs the m-tiles in two
 // passes over the same weight registers.  tools/micro/sk4.hip (graph of 28 dependent launches over distinct matrices, batch
-// 32, us per launch incl. the boundary, skinny3 -> skinny4): qkv 6.7 -> 5.4, o 5.1 -> 3.9, gate/up 13.4 -> 11.8-12.2,
-// down 8.4 -> 6.9, tied head 114.7 -> 109.5; batch 1: 5.6 -> 4.7, 4.5 -> 3.5, 12.3 -> 10.8, 7.2 -> 6.0, 100.3 -> 92.7; an
-// empty launch of the same grid costs 2.0.
+// 32, us per launch incl. the boundary, skinny3 -> skinny4): qkv 6.7 -> 5.4 (two slabs instead of four: 5.7, and faster
+// inside the step because the attention prologue adds fewer), o 5.1 -> 3.9, gate/up 13.4 -> 11.8-12.2, down 8.4 -> 6.9, tied
+// head 114.7 -> 109.5; batch 1: 5.6 -> 4.7, 4.5 -> 3.5, 12.3 -> 10.8, 7.2 -> 6.0, 100.3 -> 92.7; an empty dependent launch
+// costs 1.76 (tools/micro/empty.hip).
 // ---------------------------------------------------------------------------
 // FUSE (M <= 2): the X fragments come from LDS rows that every workgroup builds for itself from the previous GEMM's slabs
 // (fuse_norm_prologue, the arithmetic of slab_resnorm_x16_kernel) while its weights are in flight.
