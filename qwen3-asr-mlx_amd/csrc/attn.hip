@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KV_TILE * HD * 2];
     char* sK = smem;
     char* sV = smem + KV_TILE * HD * 2;
-    const int seg = blockIdx.z, head = blockIdx.y, qt = blockIdx.x;
+    // causal: a query tile's work grows with its index -- dispatch the heavy tiles of a (segment, head) first
+    const int seg = blockIdx.z, head = blockIdx.y, qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int len = p.seg_len[seg];
     if (qt * 64 >= len) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
