@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""In-situ tuning of the decode-step GEMM launch geometry: for each of the four layer GEMMs try (n_splits, waves,
-tiles_per_wave, wg_ksplit) candidates inside the real captured decode step (batch B, full-size random weights) and time
-graph replays.  Coordinate descent, one GEMM at a time.  Usage: tune_decode.py [B] [tokens] [names|all] [bf16|fp8]"""
-import itertools
+"""In-situ tuning of the decode-step GEMM launch geometry: for each projection try every instantiated skinny4 geometry
+(tiles per workgroup, k-steps per wave, waves) that fits its shape inside the real captured decode step (batch B, full-size
+random weights) and time graph replays.  Coordinate descent, one GEMM at a time.  (Round 1's version tuned skinny3's
+(n_splits, waves, tiles_per_wave, wg_ksplit); see git history.)  Usage: tune_decode.py [B] [tokens] [names|all] [bf16|fp8]"""
 import sys
 import time
 from pathlib import Path
@@ -63,49 +63,39 @@ def measure():
     return best * 1e6
 
 
-MIN_WGS = int(sys.argv[5]) if len(sys.argv) > 5 else 192
-
-
-def candidates(N, K, swiglu, direct=False):
+def candidates(N, K, epi):
+    """The instantiated skinny4 geometries (tiles per workgroup, k-steps per wave, waves) that fit the shape."""
     out = []
-    kq = 64 if WDT == "fp8" else 32
-    for S, waves, rt, ks in itertools.product((1, 2, 3, 4, 6, 8, 12, 16), (1, 2, 4), (1, 2, 4), (False, True)):
-        if K % (kq * S) or (waves == 1 and not direct):
+    for g in ops._SK4_BY_EPI[epi]:
+        tpw, nks, waves = g
+        if K % (32 * nks * waves) or (N // 16) % tpw or (WDT != "bf16" and nks % 2):
             continue
-        if (swiglu or direct) and S != 1:
+        if epi != 0 and K != 32 * nks * waves:
             continue
-        if swiglu and (rt < 2 or (N // 16) % rt):
+        if B > 32 and waves * tpw * 4 > 160:
             continue
-        if ks and (K // S) % (kq * waves):
-            continue
-        per_wg = (1 if ks else waves) * rt
-        wgs = -(-(N // 16) // per_wg) * S
-        if MIN_WGS <= wgs <= (16384 if direct else 2048) and K // S >= 128:
-            out.append((S, waves, rt, ks))
+        out.append(g)
     return out
 
 
+table = ops._TUNED4 if WDT == "bf16" else ops._TUNED4_F8
 base = measure()
-print(f"B={B}: current table {base:.1f} us/token", flush=True)
-shapes = [("qkv", qkvd, H, False, False), ("o", H, qd, False, False), ("gu", 2 * I, H, True, False), ("down", H, I, False, False),
-          ("head", t.vocab_size, H, False, True)]
+print(f"B={B} {WDT}: current skinny4 table {base:.1f} us/token", flush=True)
+shapes = [("qkv", qkvd, H, 0), ("o", H, qd, 0), ("gu", 2 * I, H, 2), ("down", H, I, 0), ("head", t.vocab_size, H, 1)]
 if len(sys.argv) > 3 and sys.argv[3] != "all":
     shapes = [sh for sh in shapes if sh[0] in sys.argv[3].split(",")]
-for name, N, K, sw, direct in shapes:
-    cur = ops._TUNED.get((N, K))
+for name, N, K, epi in shapes:
+    cur = table.get((N, K))
     res = []
-    for c in candidates(N, K, sw, direct):
-        ops._TUNED[(N, K)] = c
+    for c in candidates(N, K, epi):
+        table[(N, K)] = c
         try:
             res.append((measure(), c))
         except Exception as e:                              # noqa: BLE001
             print("  ", c, "failed:", str(e)[:80])
     res.sort()
-    print(f"{name} (N={N}, K={K}) current {cur}: best 5 of {len(res)}: " + ", ".join(f"{c} {u:.1f}" for u, c in res[:5]), flush=True)
-    one = [(u, c) for u, c in res if c[0] == 1]
-    if one and not (sw or direct):
-        print("   unsplit (n_splits = 1): " + ", ".join(f"{c} {u:.1f}" for u, c in one[:4]), flush=True)
-    ops._TUNED[(N, K)] = res[0][1] if res and res[0][0] < base - 2 else cur
+    print(f"{name} (N={N}, K={K}) current {cur}: " + ", ".join(f"{c} {u:.1f}" for u, c in res), flush=True)
+    table[(N, K)] = res[0][1] if res and res[0][0] < base - 2 else cur
     base = min(base, res[0][0]) if res else base
-print("final table:", {k: v for k, v in ops._TUNED.items()})
+print("final table:", dict(table))
 print(f"final {measure():.1f} us/token")
