@@ -55,6 +55,9 @@ for step in "$@"; do
     probe_graph)  prof probe_graph graph --pmc FETCH_SIZE --kernel-trace ;;
     probe_graph4) prof probe_graph4 graph4 --pmc FETCH_SIZE --kernel-trace ;;
     probe_regraph) prof probe_regraph regraph --pmc FETCH_SIZE --kernel-trace ;;
+    bench_stats)  rm -rf $O/${TAG}_bench_stats; run 600 $O/${TAG}_bench_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_bench_stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-extra-configs
+                  find $O/${TAG}_bench_stats -name '*kernel_trace.csv' -delete; find $O/${TAG}_bench_stats -name '*.csv' -size +20M -delete
+                  find $O/${TAG}_bench_stats -name '*kernel_stats.csv' -exec head -16 {} \; ; grep '^{' $O/${TAG}_bench_stats.log | tail -1 | cut -c1-300 ;;
     bench_pmc)    rm -rf $O/${TAG}_bench_pmc; run 600 $O/${TAG}_bench_pmc.log rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_bench_pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipeline --no-extra-configs
                   find $O/${TAG}_bench_pmc -name '*.csv' -size +1M -delete; tail -12 $O/${TAG}_bench_pmc.log ;;
     stamps)       run 300 $O/${TAG}_stamps.log python3 $R/tools/gemm_stamps.py ; cat $O/${TAG}_stamps.log ;;
