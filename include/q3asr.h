@@ -110,8 +110,10 @@ int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, const void* V
                    int n_kv_heads, int head_dim, int causal, float scale, void* stream);
 
 /* ---- generate.py:20-81  prepare_inputs ------------------------------------------------------- */
-int q3asr_embed_merge(const int32_t* ids, const int32_t* audio_src, const void* E, const float* enc, void* out,
-                      int M, int H, void* stream);
+/* E: embedding table with V rows; enc: n_enc encoder rows.  Index vectors are device-resident and cannot be validated
+ * by the host: a token id outside [0, V) or an encoder row >= n_enc yields a zero row, never an out-of-bounds read. */
+int q3asr_embed_merge(const int32_t* ids, const int32_t* audio_src, const void* E, int V, const float* enc, int n_enc,
+                      void* out, int M, int H, void* stream);
 
 /* ---- decoder.py:140-156  per-head QK-RMSNorm + nn.RoPE + KVCache.update ----------------------
  * qkv: bf16 [M][ld] (is_slab=0) or fp32 split-K slabs [n_slabs][..] (is_slab=1, ld/slab_stride in
@@ -123,7 +125,7 @@ int q3asr_qk_norm_rope_kv(const void* qkv, int is_slab, int64_t ld, int n_slabs,
                           int nh, int nkv, int head_dim, int Lmax, void* stream);
 
 /* ---- decode step (generate.py:289-313 -> decoder.py:219-253 at T=1), M = batch <= 64 --------- */
-int q3asr_embed_rmsnorm(const int32_t* tok, const void* E, void* h_out, const void* w, void* x_out, int M, int N,
+int q3asr_embed_rmsnorm(const int32_t* tok, const void* E, int V, void* h_out, const void* w, void* x_out, int M, int N,
                         float eps, void* stream);
 /* C = X[M,K] . W[N,K]^T, weight-streaming; n_splits>1 writes fp32 slabs [n_splits][M][N]. */
 int q3asr_skinny_gemm(const void* X, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, int n_splits,
@@ -170,8 +172,9 @@ int q3asr_skinny4_gemm_norm(const float* in_slab, int in_n_slabs, int64_t in_sla
 /* h = bf16(h + bf16(sum slabs)); x16 = RMSNorm(h)*w in X16 layout (decoder.py:191-196,189,251) */
 int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
                            const void* w, void* x16, int M, int N, float eps, void* stream);
-/* h = E[tok[m]] (tok NULL: h = E[m]); x16 = RMSNorm(h)*w (generate.py:294 + decoder.py:189) */
-int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_out, const void* w, void* x16, int M, int N,
+/* h = E[tok[m]] (tok NULL: h = E[m]); x16 = RMSNorm(h)*w (generate.py:294 + decoder.py:189).  E has V rows; an id outside
+ * [0, V) gathers a zero row (device-resident ids cannot be validated by the host). */
+int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, void* h_out, const void* w, void* x16, int M, int N,
                          float eps, void* stream);
 /* decode attention with decoder.py:144-156 (QK-RMSNorm, RoPE, cache append) fused into its prologue;
  * input: the qkv projection as n_slabs fp32 slabs [n_slabs][B][ld]; output att in X16 layout.
@@ -189,6 +192,9 @@ int q3asr_attn_decode(const void* q, const void* k_cache, const void* v_cache, c
                       int B, int nh, int nkv, int head_dim, int Lmax, float scale, void* stream);
 
 /* ---- generate.py:88-215 `sample` + loop bookkeeping :286-313, one launch per step ------------ */
+/* finished[b]: 0 running, 1 ended (EOS or budget), Q3ASR_ROW_FAILED: the row's logits had no valid maximum / draw (non-finite
+ * logits).  A failed row records token 0 and stops; the host raises when it reads the flag (generate.py). */
+#define Q3ASR_ROW_FAILED 2
 int q3asr_sample_step(const void* logits, int64_t ld, int B, int V, int32_t* out_tokens, int max_out,
                       int32_t* n_gen, int32_t* finished, int32_t* cur_tok, int32_t* pos, const int32_t* max_new,
                       float temperature, float top_p, int top_k, float penalty, int ctx, uint64_t seed,

@@ -5,6 +5,16 @@ output is rounded to bf16 (the checkpoint and the embeddings are bf16,
 generate.py:48), reductions/softmax in float32.  Weights keyed as in the
 checkpoint after stripping ``model.`` (decoder.py:282-288).
 PARITY UNPINNED at real weights (see oracle/__init__.py).
+
+``fp8_rows`` (BASELINE.json configs[4], "fp8 weights (CDNA4 fp8 MFMA)"): the
+first ``fp8_rows`` rows of a ``forward`` call -- the prompt rows a W8A8 prefill
+handles -- run every projection of decoder.py:92-97,136-165 in e4m3 x e4m3
+arithmetic: the weight quantised per output row with a power-of-two scale, the
+activation operand (RMSNorm output, attention output, SwiGLU output) per token
+with scale = amax / 448, products accumulated in float32 and scaled by
+a_scale[m] * w_scale[n] before the usual bf16 rounding.  Rows beyond
+``fp8_rows`` (the generated tokens of a teacher-forced pass) keep bf16
+activations against the dequantised weights, as a W8A16 decode step does.
 """
 from __future__ import annotations
 
@@ -13,6 +23,28 @@ import torch
 
 def bf(x: torch.Tensor) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+E4M3_MAX = 448.0
+
+
+def quantize_weight_rows_e4m3(W: torch.Tensor):
+    """Per-output-row power-of-two scale s with max|W[n]| / s <= 448; returns (q, s) with q the e4m3 values as float32.
+    Idempotent on an already dequantised weight (q * s reproduces it exactly)."""
+    amax = W.abs().amax(dim=1).clamp_min(1e-30)
+    s = torch.exp2(torch.ceil(torch.log2(amax / E4M3_MAX)))
+    q = (W / s[:, None]).to(torch.float8_e4m3fn).to(torch.float32)
+    return q, s
+
+
+def quantize_act_rows_e4m3(x: torch.Tensor):
+    """Per-token scale = amax / 448 (1 for an all-zero row), values rounded to e4m3 (RNE); float32 arithmetic in the
+    order a one-pass row quantiser uses: scale = amax * (1/448), inv = 1 / scale, q = e4m3(x * inv)."""
+    amax = x.abs().amax(dim=-1)
+    sc = torch.where(amax > 0, amax * torch.tensor(1.0 / E4M3_MAX, dtype=torch.float32), torch.ones_like(amax))
+    inv = 1.0 / sc
+    q = (x * inv[..., None]).to(torch.float8_e4m3fn).to(torch.float32)
+    return q, sc
 
 
 def rms_norm(x, w, eps):
@@ -42,6 +74,7 @@ class DecoderOracle:
         self.nh, self.nkv, self.hd, self.eps, self.theta = n_heads, n_kv_heads, head_dim, eps, theta
         self.n_layers = 1 + max(int(k.split(".")[1]) for k in W if k.startswith("layers."))
         self.gpu_rounding = gpu_rounding
+        self._w8 = {}                            # name -> (e4m3 values as float32, per-row scale), built on first use
         self.reset()
 
     def reset(self):
@@ -52,21 +85,33 @@ class DecoderOracle:
     def embed(self, ids) -> torch.Tensor:
         return self.W["embed_tokens.weight"][torch.as_tensor(ids, dtype=torch.long)]
 
-    def forward(self, h: torch.Tensor, last_only: bool = True, keep_from: int = None) -> torch.Tensor:
+    def _lin(self, x: torch.Tensor, name: str, n8: int) -> torch.Tensor:
+        """x @ W.T in float32 (unrounded); rows < n8 in e4m3 x e4m3 arithmetic (module docstring)."""
+        y = x @ self.W[name].T
+        if n8 > 0:
+            if name not in self._w8:
+                self._w8[name] = quantize_weight_rows_e4m3(self.W[name])
+            q, s = self._w8[name]
+            x8, sa = quantize_act_rows_e4m3(x[:n8])
+            y[:n8] = (x8 @ q.T) * (s[None, :] * sa[:, None])
+        return y
+
+    def forward(self, h: torch.Tensor, last_only: bool = True, keep_from: int = None, fp8_rows: int = 0) -> torch.Tensor:
         """h (T, hidden) bf16-valued float32; appends to the cache at
         self.offset and advances it.  Returns bf16-valued logits (T or 1, V)
         (decoder.py:243-253; the reference computes every position, only the
         last is consumed at generate.py:279)."""
         W = self.W
         T = h.shape[0]
+        n8 = min(int(fp8_rows), T)
         pos = torch.arange(self.offset, self.offset + T)
         g = self.nh // self.nkv
         for li in range(self.n_layers):
             p = f"layers.{li}."
             x = rms_norm(h, W[p + "input_layernorm.weight"], self.eps)
-            q = bf(x @ W[p + "self_attn.q_proj.weight"].T).reshape(T, self.nh, self.hd)
-            k = bf(x @ W[p + "self_attn.k_proj.weight"].T).reshape(T, self.nkv, self.hd)
-            v = bf(x @ W[p + "self_attn.v_proj.weight"].T).reshape(T, self.nkv, self.hd)
+            q = bf(self._lin(x, p + "self_attn.q_proj.weight", n8)).reshape(T, self.nh, self.hd)
+            k = bf(self._lin(x, p + "self_attn.k_proj.weight", n8)).reshape(T, self.nkv, self.hd)
+            v = bf(self._lin(x, p + "self_attn.v_proj.weight", n8)).reshape(T, self.nkv, self.hd)
             q = rms_norm(q, W[p + "self_attn.q_norm.weight"], self.eps).transpose(0, 1)   # (H,T,D)
             k = rms_norm(k, W[p + "self_attn.k_norm.weight"], self.eps).transpose(0, 1)
             v = v.transpose(0, 1)
@@ -88,12 +133,12 @@ class DecoderOracle:
             if self.gpu_rounding:
                 pr = bf(pr)
             a = bf((pr @ Vq) / l).transpose(0, 1).reshape(T, self.nh * self.hd)
-            h = bf(h + bf(a @ W[p + "self_attn.o_proj.weight"].T))
+            h = bf(h + bf(self._lin(a, p + "self_attn.o_proj.weight", n8)))
             x = rms_norm(h, W[p + "post_attention_layernorm.weight"], self.eps)
-            gt = bf(x @ W[p + "mlp.gate_proj.weight"].T)
-            up = bf(x @ W[p + "mlp.up_proj.weight"].T)
+            gt = bf(self._lin(x, p + "mlp.gate_proj.weight", n8))
+            up = bf(self._lin(x, p + "mlp.up_proj.weight", n8))
             act = bf(gt * torch.sigmoid(gt) * up)
-            h = bf(h + bf(act @ W[p + "mlp.down_proj.weight"].T))
+            h = bf(h + bf(self._lin(act, p + "mlp.down_proj.weight", n8)))
         self.offset += T
         if keep_from is not None:               # teacher-forced checks: logits of rows keep_from.. only
             h = h[keep_from:]

@@ -32,16 +32,16 @@ _SIGS = {
     "q3asr_layernorm_f32_bf16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_rmsnorm_bf16": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _f, _vp],
     "q3asr_attn_fwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
-    "q3asr_embed_merge": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "q3asr_embed_merge": [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "q3asr_qk_norm_rope_kv": [_vp, _i, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "q3asr_embed_rmsnorm": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "q3asr_embed_rmsnorm": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_skinny_gemm": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_skinny3_gemm": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_skinny4_gemm": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_skinny4_gemm_norm": [_vp, _i, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_skinny3_gemm_norm": [_vp, _i, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_slab_resnorm_x16": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
-    "q3asr_embed_norm_x16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "q3asr_embed_norm_x16": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_attn_decode_fused_workspace": [_i, _i, _i],
     "q3asr_attn_decode_force_valu": [_i],
     "q3asr_attn_decode_fused": [_vp, _i64, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],

@@ -167,25 +167,40 @@ def get_frontend(device=None, sample_rate: int = SAMPLE_RATE, f_min: float = F_M
     return fe
 
 
-_staging = threading.local()     # per thread (= per lane): a pinned host buffer that outlives the call, and the event of its last copy
+# Pinned staging buffers for the H2D copy of a request, pooled per (device, lane): a lane is one request stream
+# (decoder.set_lane), so its buffer is reused from call to call whichever short-lived worker thread serves it; the event of
+# the last copy that read a buffer guards its reuse.  release_staging() (Qwen3ASR.close) gives the pinned memory back.
+_staging: dict = {}
+_staging_lock = threading.Lock()
+_STAGING_MIN = 1 << 20            # floats
+
+
+def release_staging() -> None:
+    with _staging_lock:
+        _staging.clear()
 
 
 def pack_audio(batch: Sequence[np.ndarray], device):
     """Host list of 1-D float32 arrays -> (padded device tensor [B][Lmax], lens device, lens host).
-    The rows are staged in a pinned buffer kept per thread (allocating 61 MB of pinned memory per 32 x 30 s request cost
-    4-25 ms of a 250 ms request); the buffer is reused only after the copy that last read it has completed."""
+    On a GPU device the rows are staged in a pinned buffer kept per (device, lane) (allocating 61 MB of pinned memory per
+    32 x 30 s request cost 4-25 ms of a 250 ms request); the buffer is reused only after the copy that last read it has
+    completed.  A CPU device gets a plain tensor of its own."""
     import torch
     lens = [int(len(a)) for a in batch]
     lmax = max(lens)
     n = len(batch) * lmax
-    if not torch.cuda.is_available():
+    dev_t = torch.device(device)
+    if dev_t.type != "cuda":
         host = torch.zeros((len(batch), lmax), dtype=torch.float32)
         for i, a in enumerate(batch):
             host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-        return host.to(device), torch.tensor(lens, dtype=torch.int32).to(device), lens
-    st = getattr(_staging, "buf", None)
+        return host.to(dev_t), torch.tensor(lens, dtype=torch.int32).to(dev_t), lens
+    from .decoder import current_lane
+    key = (dev_t.index if dev_t.index is not None else torch.cuda.current_device(), current_lane())
+    with _staging_lock:
+        st = _staging.pop(key, None)                       # taken out while in use: a second thread on the same lane gets its own
     if st is None or st[0].numel() < n:
-        st = _staging.buf = (torch.empty((max(n, 1 << 20),), dtype=torch.float32, pin_memory=True), None)
+        st = (torch.empty((max(n, _STAGING_MIN),), dtype=torch.float32, pin_memory=True), None)
     flat, ev = st
     if ev is not None:
         ev.synchronize()                                   # the previous request's H2D copy has read the buffer
@@ -194,11 +209,12 @@ def pack_audio(batch: Sequence[np.ndarray], device):
         host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
         if lens[i] < lmax:
             host[i, lens[i]:] = 0.0
-    dev = host.to(device, non_blocking=True)
-    lens_dev = torch.tensor(lens, dtype=torch.int32).to(device, non_blocking=True)
+    dev = host.to(dev_t, non_blocking=True)
+    lens_dev = torch.tensor(lens, dtype=torch.int32).to(dev_t, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev.device))
-    _staging.buf = (flat, ev)
+    with _staging_lock:
+        _staging[key] = (flat, ev)
     return dev, lens_dev, lens
 
 

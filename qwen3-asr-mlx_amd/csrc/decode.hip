@@ -690,22 +690,27 @@ extern "C" int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t sl
 }
 
 // h = E[tok[m]] (or a given bf16 row when tok == nullptr); x16 = RMSNorm(h) * w   (generate.py:294 + decoder.py:189)
+// Row ids come from device memory the C-ABI cannot validate: an id outside [0, V) gathers nothing (h = 0, x = 0) instead of
+// reading out of bounds -- the policy of the cache-row writes (fault records).
 template <int EPT>
 __global__ __launch_bounds__(256) void embed_norm_x16_kernel(const int* __restrict__ tok, const bf16* __restrict__ E,
                                                              bf16* __restrict__ h_out, const bf16* __restrict__ w,
-                                                             bf16* __restrict__ x16, int MT, float eps) {
+                                                             bf16* __restrict__ x16, int MT, float eps, int V) {
     __shared__ float red[4];
     constexpr int N = 256 * EPT;
     constexpr int NV = N / 8;
     const int m = blockIdx.x;
-    const bf16* src = E + (long)(tok ? tok[m] : m) * N;
+    const int id = tok ? tok[m] : m;
+    const bool ok = (unsigned)id < (unsigned)V;                        // uniform per workgroup
+    const bf16* src = E + (long)(ok ? id : 0) * N;
     float q2 = 0.f;
     float hv[(NV + 255) / 256][8];
 #pragma unroll
     for (int it = 0; it < (NV + 255) / 256; ++it) {
         const int v = threadIdx.x + 256 * it;
         if (v < NV) {
-            const bf16x8 hi = *reinterpret_cast<const bf16x8*>(src + 8 * v);
+            bf16x8 hi = bf16x8{};
+            if (ok) hi = *reinterpret_cast<const bf16x8*>(src + 8 * v);
             *reinterpret_cast<bf16x8*>(h_out + (long)m * N + 8 * v) = hi;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { hv[it][e] = bf2f(hi[e]); q2 = fmaf(hv[it][e], hv[it][e], q2); }
@@ -728,19 +733,20 @@ __global__ __launch_bounds__(256) void embed_norm_x16_kernel(const int* __restri
     }
 }
 
-extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, void* h_out, const void* w, void* x16, int M, int N,
+extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, void* h_out, const void* w, void* x16, int M, int N,
                                     float eps, void* stream) {
     Q3_REQUIRE(E && h_out && w && x16, "embed_norm_x16: null pointer");
     Q3_REQUIRE(M > 0 && M <= 64 && (N == 512 || N == 1024 || N == 2048 || N == 4096), "embed_norm_x16: M=%d N=%d unsupported", M, N);
+    Q3_REQUIRE(V > 0 && (tok || V >= M), "embed_norm_x16: E has V=%d rows (M=%d rows are read when tok is NULL)", V, M);
     const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     dim3 grid(M), blk(256);
     hipStream_t s = (hipStream_t)stream;
     const bf16* e = (const bf16*)E; bf16* ho = (bf16*)h_out; const bf16* ww = (const bf16*)w; bf16* xo = (bf16*)x16;
     switch (N / 256) {
-        case 2: hipLaunchKernelGGL(embed_norm_x16_kernel<2>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps); break;
-        case 4: hipLaunchKernelGGL(embed_norm_x16_kernel<4>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps); break;
-        case 8: hipLaunchKernelGGL(embed_norm_x16_kernel<8>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps); break;
-        default: hipLaunchKernelGGL(embed_norm_x16_kernel<16>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps); break;
+        case 2: hipLaunchKernelGGL(embed_norm_x16_kernel<2>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps, V); break;
+        case 4: hipLaunchKernelGGL(embed_norm_x16_kernel<4>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps, V); break;
+        case 8: hipLaunchKernelGGL(embed_norm_x16_kernel<8>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps, V); break;
+        default: hipLaunchKernelGGL(embed_norm_x16_kernel<16>, grid, blk, 0, s, tok, e, ho, ww, xo, MT, eps, V); break;
     }
     return q3_check_launch("embed_norm_x16");
 }

@@ -99,13 +99,19 @@ extern "C" int q3asr_conv1_gelu_f32(const float* mel, int Fmax, const int32_t* c
 
 // ---------------------------------------------------------------------------
 // prepare_inputs (generate.py:20-81): out[m] = audio_src[m] >= 0 ? bf16(enc[audio_src[m]]) : E[ids[m]].
+// The index vectors live in device memory the C-ABI cannot validate: an encoder row >= n_enc or a token id outside [0, V)
+// yields a zero row instead of an out-of-bounds read.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_merge_kernel(const int* __restrict__ ids, const int* __restrict__ audio_src,
                                                           const bf16* __restrict__ E, const float* __restrict__ enc,
-                                                          bf16* __restrict__ out, int H) {
+                                                          bf16* __restrict__ out, int H, int V, int n_enc) {
     const long m = blockIdx.x;
     const int a = audio_src[m];
     bf16* o = out + m * H;
+    if ((a >= 0 && a >= n_enc) || (a < 0 && (unsigned)ids[m] >= (unsigned)V)) {          // uniform per workgroup
+        for (int i = threadIdx.x * 8; i < H; i += 2048) *reinterpret_cast<uint4*>(o + i) = uint4{0u, 0u, 0u, 0u};
+        return;
+    }
     if (a >= 0) {
         const float* src = enc + (long)a * H;
         for (int i = threadIdx.x * 4; i < H; i += 1024) {
@@ -122,12 +128,12 @@ __global__ __launch_bounds__(256) void embed_merge_kernel(const int* __restrict_
     }
 }
 
-extern "C" int q3asr_embed_merge(const int32_t* ids, const int32_t* audio_src, const void* E, const float* enc, void* out,
-                                 int M, int H, void* stream) {
+extern "C" int q3asr_embed_merge(const int32_t* ids, const int32_t* audio_src, const void* E, int V, const float* enc, int n_enc,
+                                 void* out, int M, int H, void* stream) {
     Q3_REQUIRE(ids && audio_src && E && out, "embed_merge: null pointer");
-    Q3_REQUIRE(M > 0 && H % 8 == 0, "embed_merge: M=%d H=%d", M, H);
+    Q3_REQUIRE(M > 0 && H % 8 == 0 && V > 0 && n_enc >= 0 && (enc || n_enc == 0), "embed_merge: M=%d H=%d V=%d n_enc=%d", M, H, V, n_enc);
     hipLaunchKernelGGL(embed_merge_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, ids, audio_src, (const bf16*)E, enc,
-                       (bf16*)out, H);
+                       (bf16*)out, H, V, n_enc);
     return q3_check_launch("embed_merge");
 }
 

@@ -172,15 +172,19 @@ __device__ __forceinline__ void penalty_setup(const SampleParams& p, const bf16*
 
 // bookkeeping (generate.py:286-313): EOS is recorded, then the sequence stops
 __device__ __forceinline__ void commit_token(const SampleParams& p, int b, int n, int token) {
-    // A row of NaN logits (a diverged model, a corrupt checkpoint) has no maximum and no sampled index: the sentinel must not
-    // reach the embedding gather of the next step as a row number.  Such a row emits token 0 (results are meaningless either way).
-    if (token < 0 || token >= p.V) token = 0;
+    // A row of NaN logits (a diverged model, a corrupt checkpoint, a kernel fault upstream) has no maximum and no sampled
+    // index.  The sentinel must not reach the embedding gather of the next step as a row number: the row records token 0,
+    // stops, and its `finished` flag becomes Q3ASR_ROW_FAILED (2) instead of 1 -- the device-side error flag the host looks
+    // at whenever it reads `finished` (generate.py raises Q3AsrError naming the row; include/q3asr.h).
+    const bool bad = token < 0 || token >= p.V;
+    if (bad) token = 0;
     if (!p.finished[b]) {
         if (n < p.max_out) p.out_tokens[(long)b * p.max_out + n] = token;
         const int n1 = n + 1;
         p.n_gen[b] = n1;
         p.cur_tok[b] = token;
-        if (token == p.eos0 || token == p.eos1 || n1 >= p.max_new[b] || n1 >= p.max_out) p.finished[b] = 1;
+        if (bad) p.finished[b] = 2;
+        else if (token == p.eos0 || token == p.eos1 || n1 >= p.max_new[b] || n1 >= p.max_out) p.finished[b] = 1;
         else p.pos[b] = p.pos[b] + 1;
     }
 }

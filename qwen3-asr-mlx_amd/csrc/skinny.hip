@@ -230,17 +230,18 @@ extern "C" int q3asr_slab_swiglu(const float* slab, int n_slabs, int64_t slab_st
 template <int EPT>
 __global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const int* __restrict__ tok, const bf16* __restrict__ E,
                                                             bf16* __restrict__ h_out, const bf16* __restrict__ w,
-                                                            bf16* __restrict__ x_out, float eps) {
+                                                            bf16* __restrict__ x_out, float eps, int V) {
     __shared__ float red[4];
     constexpr int N = 256 * EPT;
     const long m = blockIdx.x;
     const int c0 = threadIdx.x * EPT;
-    const bf16* src = E + (long)tok[m] * N + c0;
+    const bool ok = (unsigned)tok[m] < (unsigned)V;                    // an id outside [0, V) gathers a zero row
+    const bf16* src = E + (long)(ok ? tok[m] : 0) * N + c0;
     float v[EPT];
     float q = 0.f;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
-        const bf16 hv = src[e];
+        const bf16 hv = ok ? src[e] : f2bf(0.f);
         h_out[m * N + c0 + e] = hv;
         v[e] = bf2f(hv);
         q = fmaf(v[e], v[e], q);
@@ -253,18 +254,18 @@ __global__ __launch_bounds__(256) void embed_rmsnorm_kernel(const int* __restric
     for (int e = 0; e < EPT; ++e) x_out[m * N + c0 + e] = f2bf(v[e] * r * bf2f(w[c0 + e]));
 }
 
-extern "C" int q3asr_embed_rmsnorm(const int32_t* tok, const void* E, void* h_out, const void* w, void* x_out, int M, int N,
+extern "C" int q3asr_embed_rmsnorm(const int32_t* tok, const void* E, int V, void* h_out, const void* w, void* x_out, int M, int N,
                                    float eps, void* stream) {
-    Q3_REQUIRE(tok && E && h_out && w && x_out, "embed_rmsnorm: null pointer");
+    Q3_REQUIRE(tok && E && h_out && w && x_out && V > 0, "embed_rmsnorm: null pointer or V <= 0");
     Q3_REQUIRE(M > 0 && (N == 512 || N == 1024 || N == 2048 || N == 4096), "embed_rmsnorm: N=%d unsupported", N);
     dim3 grid(M), blk(256);
     hipStream_t s = (hipStream_t)stream;
     const bf16* e = (const bf16*)E; bf16* ho = (bf16*)h_out; const bf16* ww = (const bf16*)w; bf16* xo = (bf16*)x_out;
     switch (N / 256) {
-        case 2: hipLaunchKernelGGL(embed_rmsnorm_kernel<2>, grid, blk, 0, s, tok, e, ho, ww, xo, eps); break;
-        case 4: hipLaunchKernelGGL(embed_rmsnorm_kernel<4>, grid, blk, 0, s, tok, e, ho, ww, xo, eps); break;
-        case 8: hipLaunchKernelGGL(embed_rmsnorm_kernel<8>, grid, blk, 0, s, tok, e, ho, ww, xo, eps); break;
-        default: hipLaunchKernelGGL(embed_rmsnorm_kernel<16>, grid, blk, 0, s, tok, e, ho, ww, xo, eps); break;
+        case 2: hipLaunchKernelGGL(embed_rmsnorm_kernel<2>, grid, blk, 0, s, tok, e, ho, ww, xo, eps, V); break;
+        case 4: hipLaunchKernelGGL(embed_rmsnorm_kernel<4>, grid, blk, 0, s, tok, e, ho, ww, xo, eps, V); break;
+        case 8: hipLaunchKernelGGL(embed_rmsnorm_kernel<8>, grid, blk, 0, s, tok, e, ho, ww, xo, eps, V); break;
+        default: hipLaunchKernelGGL(embed_rmsnorm_kernel<16>, grid, blk, 0, s, tok, e, ho, ww, xo, eps, V); break;
     }
     return q3_check_launch("embed_rmsnorm");
 }

@@ -378,13 +378,13 @@ class TextDecoder:
         if self.decode_impl != "v3" and getattr(self, "fp8_prefill", False):
             raise NotImplementedError("decode_impl 'v1' reads row-major bf16 weights; weight_dtype='fp8' keeps none (use 'fp8w')")
         if self.decode_impl == "v3":
-            ops.call("q3asr_embed_norm_x16", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
+            ops.call("q3asr_embed_norm_x16", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), cfg.vocab_size, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
                      ops.ptr(ws.x16), B, H, eps, ops.sp())
             self._layers_decode_v3(ws, cache, ws.pos)
             self._gemm3(ws, "head", ws.x16, w, "embed", cfg.vocab_size, H, 1, out=ws.logits)
             self.sample_step(ws, ws.logits, sampling)
             return
-        ops.call("q3asr_embed_rmsnorm", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
+        ops.call("q3asr_embed_rmsnorm", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), cfg.vocab_size, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
                  ops.ptr(ws.x), B, H, eps, ops.sp())
         for li, L in enumerate(layers):
             self._skinny_slab(ws.x, B, L["wqkv"], qkvd, H, sp["qkv"], ws.slab)
@@ -608,7 +608,7 @@ class TextDecoder:
         ws.pos.fill_(off)
         layers = w["layers"]
         if self.decode_impl == "v3":
-            ops.call("q3asr_embed_norm_x16", None, ops.ptr(h), ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]), ops.ptr(ws.x16), 1, H,
+            ops.call("q3asr_embed_norm_x16", None, ops.ptr(h), 1, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]), ops.ptr(ws.x16), 1, H,
                      eps, ops.sp())
             self._layers_decode_v3(ws, cache, ws.pos)
             return ops.from_x16(ws.x16, 1, ws.MT).contiguous()

@@ -29,22 +29,37 @@ def run_sharded(run_fn: Callable, audios, max_tokens: Optional[Sequence[int]], d
     -> list[list[int]]`` on its share (no host bounce of the audio).  Rank 0 returns the token lists in request order, the
     others None.  The result is identical to one rank running the whole request whenever run_fn is batch-invariant (the HIP
     path is).  An exception inside run_fn on any rank is carried through the gather: every rank completes the
-    collectives, rank 0 raises RuntimeError naming the failing ranks, the failing ranks re-raise their own exception."""
+    collectives, rank 0 raises RuntimeError naming the failing ranks, the failing ranks re-raise their own exception.
+    A malformed request (rank 0's validation) travels in the header broadcast, so every rank raises ValueError together
+    and none is left waiting in a collective."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     hdr = torch.zeros(3, dtype=torch.int64, device=device)
+    bad_request = None
     if rank == 0:
-        resident = isinstance(audios, tuple) and len(audios) == 2 and hasattr(audios[0], "shape") and not isinstance(audios[0], np.ndarray)
-        lens = [int(n) for n in audios[1]] if resident else [len(a) for a in audios]
-        if len(max_tokens) != len(lens):
-            raise ValueError("run_sharded: one max_tokens entry per utterance")
-        parts = assign(lens, world)
-        n_max = max(len(p) for p in parts)
-        l_max = max(lens) if lens else 0
-        hdr = torch.tensor([n_max, l_max, max(max_tokens) if len(lens) else 0], dtype=torch.int64, device=device)
+        try:
+            resident = isinstance(audios, tuple) and len(audios) == 2 and hasattr(audios[0], "shape") and not isinstance(audios[0], np.ndarray)
+            lens = [int(n) for n in audios[1]] if resident else [len(a) for a in audios]
+            if max_tokens is None or len(max_tokens) != len(lens):
+                raise ValueError("run_sharded: one max_tokens entry per utterance")
+            if resident and (audios[0].ndim != 2 or audios[0].shape[0] != len(lens) or (lens and max(lens) > audios[0].shape[1])):
+                raise ValueError("run_sharded: resident audio must be [n][l] with every length <= l")
+            if any(int(m) < 1 for m in max_tokens):
+                raise ValueError("run_sharded: max_tokens must be >= 1")
+            parts = assign(lens, world)
+            n_max = max(len(p) for p in parts)
+            l_max = max(lens) if lens else 0
+            hdr = torch.tensor([n_max, l_max, max(max_tokens) if len(lens) else 0], dtype=torch.int64, device=device)
+        except Exception as e:                                # noqa: BLE001 -- the other ranks are already in the broadcast
+            bad_request = e
+            hdr = torch.tensor([-1, 0, 0], dtype=torch.int64, device=device)
     dist.broadcast(hdr, 0, group=group)
     n_max, l_max, t_max = (int(v) for v in hdr.tolist())
+    if n_max < 0:
+        if bad_request is not None:
+            raise bad_request if isinstance(bad_request, ValueError) else ValueError(f"run_sharded: {bad_request}")
+        raise ValueError("run_sharded: rank 0 rejected the request")
     if n_max == 0:
         return [] if rank == 0 else None
     my_audio = torch.zeros((n_max, l_max), dtype=torch.float32, device=device)

@@ -38,8 +38,8 @@ def _merge(enc_feats, ids_per_seq: Sequence[Sequence[int]], tok_counts: Sequence
     H = decoder.config.hidden_size
     out = torch.empty((len(ids), H), dtype=torch.bfloat16, device=dev)
     enc = enc_feats if enc_feats is not None and enc_feats.numel() else None
-    ops.call("q3asr_embed_merge", ops.ptr(ids_t), ops.ptr(src_t), ops.ptr(decoder.w["embed"]), ops.ptr(enc), ops.ptr(out),
-             len(ids), H, ops.sp())
+    ops.call("q3asr_embed_merge", ops.ptr(ids_t), ops.ptr(src_t), ops.ptr(decoder.w["embed"]), int(decoder.w["embed"].shape[0]), ops.ptr(enc),
+             0 if enc is None else int(enc.shape[0]), ops.ptr(out), len(ids), H, ops.sp())
     return out
 
 
@@ -148,10 +148,25 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
                 done += 1
                 if done % 16 == 0 and bool(ws.finished.all()):
                     break
-    n_gen = ws.n_gen.tolist()
+    state = torch.stack([ws.n_gen, ws.finished]).tolist()            # one device-to-host copy for both counters
+    n_gen = state[0]
+    _raise_failed_rows([b for b in range(B) if state[1][b] == ROW_FAILED], n_gen)
     toks = ws.out_tokens.cpu()
     out = [toks[b, : n_gen[b]].tolist() for b in range(B)]
     return (out, ws, cache) if return_state else out
+
+
+ROW_FAILED = 2                # include/q3asr.h Q3ASR_ROW_FAILED: the device-side error flag in `finished`
+
+
+def _raise_failed_rows(rows, n_gen) -> None:
+    """A row whose logits had no valid maximum / draw (NaN or all -inf: a diverged or corrupt checkpoint, a fault upstream)
+    stops on the device with finished = ROW_FAILED; the reference would silently go on decoding garbage (mx.argmax of NaN).
+    Raised here so that it is never mistaken for a transcript."""
+    if rows:
+        from ._lib import Q3AsrError
+        where = ", ".join(f"row {r} at generated token {max(0, int(n_gen[r]) - 1)}" for r in rows[:8])
+        raise Q3AsrError(f"non-finite logits: {where} (the decoder produced no valid maximum; check the checkpoint)")
 
 
 _RESERVED = object()          # RowScheduler: row being prefilled on the admission stream
@@ -303,7 +318,8 @@ class RowScheduler:
             self._fresh = True
 
     def harvest(self) -> list:
-        """[(key, token ids)] of the sequences that have ended (EOS or budget); their rows become free."""
+        """[(key, token ids)] of the sequences that have ended (EOS or budget); their rows become free.  A sequence whose row
+        raised the device-side error flag (non-finite logits) comes back as (key, Q3AsrError) instead of ids."""
         import torch
         self._look()
         ended = [r for r in range(self.B) if self.owner[r] is not None and self.owner[r] is not _RESERVED and self._fin[r]]
@@ -313,6 +329,12 @@ class RowScheduler:
             toks = self.ws.out_tokens[torch.tensor(ended, dtype=torch.long, device=self.dev)].cpu()
         out = []
         for j, r in enumerate(ended):
+            if self._fin[r] == ROW_FAILED:                   # device-side error flag: this sequence fails, its neighbours go on
+                from ._lib import Q3AsrError
+                out.append((self.owner[r], Q3AsrError(f"non-finite logits at generated token {max(0, self._ngen[r] - 1)} "
+                                                      "(the decoder produced no valid maximum; check the checkpoint)")))
+                self.owner[r] = None
+                continue
             out.append((self.owner[r], toks[j, : self._ngen[r]].tolist()))
             self.stats["row_steps_used"] += self._ngen[r]
             self.owner[r] = None
@@ -378,6 +400,9 @@ def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence
     out: list = [None] * n
     while True:
         for key, toks in sch.harvest():
+            if isinstance(toks, Exception):
+                sch.finish()
+                raise toks
             out[key] = toks
         sch.poll(wait=not sch.active())                                    # an admission in flight: activate it when it is done
         free = sch.free_rows()

@@ -171,6 +171,8 @@ class Qwen3ASR:
         """Release weights (reference model.py:261-269)."""
         self._encoder = None  # type: ignore[assignment]
         self._decoder = None  # type: ignore[assignment]
+        from .audio import release_staging
+        release_staging()                                     # pinned H2D staging buffers
         gc.collect()
         try:
             import torch

@@ -248,8 +248,16 @@ class ContinuousTranscriber:
             pass
         return items, stop
 
-    def _resolve(self, key, tokens: list) -> None:
+    def _resolve(self, key, tokens) -> None:
         req, k = key
+        if isinstance(tokens, Exception):                     # the row raised the device-side error flag: this request fails alone
+            if not req["future"].done():
+                req["future"].set_exception(tokens)
+            req["left"] -= 1
+            return
+        if req["future"].done():                              # an earlier segment of this request failed
+            req["left"] -= 1
+            return
         req["texts"][k] = self.model._decode_output(tokens)
         req["left"] -= 1
         if req["left"] == 0:

@@ -170,6 +170,15 @@ def _worker_many(rank, world, port, q, mode):
             if rank == 0:
                 m = _StandInModel()
                 q.put(("ok", [r.text for r in res] == [m._decode_output(t) for t in _fake_run(audios, [4] * n)]))
+        elif mode == "badreq":                                         # rank 0's validation fails BEFORE the first collective
+            try:
+                qd.run_sharded(_fake_run_packed, audios if rank == 0 else None, budgets[:-1] if rank == 0 else None)
+                q.put((rank, "no error"))
+            except Exception as e:                                     # noqa: BLE001
+                q.put((rank, f"{type(e).__name__}: {e}"))
+            res = qd.run_sharded(_fake_run_packed, audios if rank == 0 else None, budgets if rank == 0 else None)   # the group is still usable
+            if rank == 0:
+                q.put(("after", res == _fake_run(audios, budgets)))
         else:                                                          # one rank's run function raises: nobody may hang
             def run(audio, lens, b):
                 if rank == 1:
@@ -213,3 +222,16 @@ def test_failing_rank_does_not_deadlock_the_group():
         assert p.exitcode == 0
     assert got[1] == "ValueError: clip shorter than one hop"
     assert got[0].startswith("RuntimeError: run_sharded: rank 1: ValueError: clip shorter than one hop")
+
+
+def test_malformed_request_raises_on_every_rank_without_a_hang():
+    """rank 0's request validation used to raise before the header broadcast while the other ranks were
+    already waiting in it.  The verdict now travels in the header: all ranks raise ValueError, and the group goes on."""
+    q, procs = _spawn(_worker_many, 2, 29900 + (os.getpid() % 90), "badreq")
+    got = dict(q.get(timeout=180) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == "ValueError: run_sharded: one max_tokens entry per utterance"
+    assert got[1] == "ValueError: run_sharded: rank 0 rejected the request"
+    assert got["after"] is True

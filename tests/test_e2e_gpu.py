@@ -460,6 +460,44 @@ def test_real_checkpoint_harness_plumbing(dev, tmp_path, capsys):
     assert "diverges at token 3" in out and "1/2 utterances token-identical; 1/2 first-position logit checks passed" in out
 
 
+def test_real_checkpoint_harness_against_oracle_outputs(dev, tmp_path, capsys):
+    """SURVEY.md section 8f rank 1 with a reference file the ORACLE produced: the harness (from_pretrained on a model
+    directory, load_audio on WAV files, greedy tokens, first-position logits) runs the HIP path and compares it with
+    tokens and `first_logits_top5` computed by the CPU restatement from the same files -- reading the checkpoint with
+    safetensors, the WAVs with numpy and the tokenizer file with `tokenizers`, nothing of the product package.  This is
+    the role an MLX capture would play (reference model.py:151-188 -> generate.py:222-315)."""
+    import json
+    import struct
+    import check_real_checkpoint as crc
+    import oracle
+    from safetensors.torch import load_file
+    from tokenizers import Tokenizer as HFTokenizer
+    from qwen3_asr_mlx_amd import synth
+    cfg = synth.small_config()
+    d = synth.write_model_dir(tmp_path / "m", cfg, seed=11, bias_std=0.02, norm_jitter=0.1, embed_std=0.08)
+    state = load_file(str(d / "model.safetensors"))
+    enc, dec = _oracle_parts(cfg, state)
+    lang_ids = HFTokenizer.from_file(str(d / "tokenizer.json")).encode(" English").ids
+    items, n_tok = [], 48
+    for i, n in enumerate((16000, 40000, 131072)):
+        x = signal("speechlike", n, seed=970 + i)
+        pcm = np.clip(np.round(x * 32767.0), -32768, 32767).astype("<i2")
+        fmt = struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", 2 * len(pcm)) + pcm.tobytes()
+        (tmp_path / f"o{i}.wav").write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+        samples = pcm.astype(np.float32) / 32768.0                           # PCM16 -> float32 (reference audio.py:150-152)
+        feats = enc(oracle.log_mel_spectrogram(samples))
+        prompt = oracle.build_prompt(feats.shape[0], lang_ids)
+        toks, logits = oracle.generate(dec, feats, prompt, max_tokens=n_tok, repetition_penalty=1.2, return_logits=True)
+        top = torch.topk(logits[0], 5)
+        items.append({"audio": f"o{i}.wav", "language": "en", "tokens": toks, "max_tokens": n_tok,
+                      "first_logits_top5": [[int(a), float(b)] for a, b in zip(top.indices, top.values)]})
+    (tmp_path / "ref.json").write_text(json.dumps(items))
+    rc = crc.main([str(d), str(tmp_path / "ref.json"), "--logit-atol", "0.0625"])     # 2 bf16 ulps at |logit| ~ 4 (small config)
+    out = capsys.readouterr().out
+    assert rc == 0 and "3/3 utterances token-identical; 3/3 first-position logit checks passed" in out, out
+
+
 # ----------------------------------------------------------------------------- BASELINE.json configs[4]: fp8 weights, long-form, sampling
 def _effective_state(state, cfg):
     """Checkpoint with the decoder projections / embedding replaced by their fp8-dequantised values."""
@@ -606,6 +644,28 @@ def test_pack_audio_reuses_its_pinned_buffer_only_after_the_copy(dev):
         for i, a in enumerate(r):
             assert np.array_equal(host[i, : len(a)], a.astype(np.float32))
             assert not host[i, len(a):].any()
+    # the buffer belongs to the (device, lane), not to the thread: short-lived worker threads of one lane share it
+    import threading
+    from qwen3_asr_mlx_amd import audio as A
+    from qwen3_asr_mlx_amd.decoder import set_lane
+    assert len(A._staging) == 1
+    seen = []
+
+    def worker():
+        set_lane(3)
+        q.audio.pack_audio(reqs[1], dev)
+        seen.append(A._staging[(dev.index or 0, 3)][0].data_ptr())
+    for _ in range(2):
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+    assert seen[0] == seen[1] and len(A._staging) == 2
+    # a CPU device never touches the pinned pool and gets memory of its own
+    c1, _, _ = q.audio.pack_audio(reqs[3], "cpu")
+    c2, _, _ = q.audio.pack_audio([signal("noise", 1600, seed=1)], "cpu")
+    assert c1.device.type == "cpu" and c1.data_ptr() != c2.data_ptr() and np.array_equal(c1[0].numpy(), reqs[3][0])
+    A.release_staging()
+    assert not A._staging
 
 
 def test_generate_reference_signature(dev, small):

@@ -538,10 +538,18 @@ def test_embed_merge(dev):
     ids = torch.tensor([3, 7, 299, 299, 0, 299, 299, 299, 8], dtype=torch.int32, device=dev)
     src = torch.tensor([-1, -1, 0, 1, -1, 2, 3, 4, -1], dtype=torch.int32, device=dev)
     out = torch.empty((9, H), dtype=torch.bfloat16, device=dev)
-    ops.call("q3asr_embed_merge", ops.ptr(ids), ops.ptr(src), ops.ptr(E), ops.ptr(enc), ops.ptr(out), 9, H, ops.sp())
+    ops.call("q3asr_embed_merge", ops.ptr(ids), ops.ptr(src), ops.ptr(E), V, ops.ptr(enc), 5, ops.ptr(out), 9, H, ops.sp())
     for m in range(9):
         want = enc[src[m]].to(torch.bfloat16) if src[m] >= 0 else E[ids[m]]
         assert torch.equal(out[m], want)
+    # indices the host cannot validate (device-resident): ids outside [0, V) and encoder rows >= n_enc give zero rows,
+    # never an out-of-bounds read (0x7fffffff is the greedy sampler's "no maximum" sentinel)
+    bad_ids = torch.tensor([3, V, -1, 0x7fffffff, 299, 299], dtype=torch.int32, device=dev)
+    bad_src = torch.tensor([-1, -1, -1, -1, 5, 4], dtype=torch.int32, device=dev)
+    out2 = torch.full((6, H), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.call("q3asr_embed_merge", ops.ptr(bad_ids), ops.ptr(bad_src), ops.ptr(E), V, ops.ptr(enc), 5, ops.ptr(out2), 6, H, ops.sp())
+    assert torch.equal(out2[0], E[3]) and torch.equal(out2[5], enc[4].to(torch.bfloat16))
+    assert not out2[1:5].any()
 
 
 # ----------------------------------------------------------------------------- decode-step kernels
@@ -592,7 +600,7 @@ def test_slab_consumers_and_embed_rmsnorm(dev):
     torch.testing.assert_close(act.float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=1e-3, rtol=8e-3)
     E = rnd((50, N), dev, 124)
     tok = torch.tensor([3, 49, 0, 3, 7], dtype=torch.int32, device=dev)
-    ops.call("q3asr_embed_rmsnorm", ops.ptr(tok), ops.ptr(E), ops.ptr(ho), ops.ptr(w), ops.ptr(xo), M, N, 1e-6, ops.sp())
+    ops.call("q3asr_embed_rmsnorm", ops.ptr(tok), ops.ptr(E), 50, ops.ptr(ho), ops.ptr(w), ops.ptr(xo), M, N, 1e-6, ops.sp())
     assert torch.equal(ho, E[tok.long()])
     torch.testing.assert_close(xo.float().cpu(), od.rms_norm(E[tok.long()].float().cpu(), w.float().cpu(), 1e-6), atol=0, rtol=8e-3)
 
@@ -762,10 +770,19 @@ def test_slab_resnorm_and_embed_norm_x16(dev, M, N, S):
     torch.testing.assert_close(ops.from_x16(x16, M).float().cpu(), xr, atol=0, rtol=8e-3)
     E = rnd((50, N), dev, 124)
     tok = torch.randint(0, 50, (M,), dtype=torch.int32).to(dev)
-    ops.call("q3asr_embed_norm_x16", ops.ptr(tok), ops.ptr(E), ops.ptr(ho), ops.ptr(w), ops.ptr(x16), M, N, 1e-6, ops.sp())
+    ops.call("q3asr_embed_norm_x16", ops.ptr(tok), ops.ptr(E), 50, ops.ptr(ho), ops.ptr(w), ops.ptr(x16), M, N, 1e-6, ops.sp())
     assert torch.equal(ho, E[tok.long()])
     torch.testing.assert_close(ops.from_x16(x16, M).float().cpu(), od.rms_norm(E[tok.long()].float().cpu(), w.float().cpu(), 1e-6),
                                atol=0, rtol=8e-3)
+    # an id outside [0, V) (e.g. the sampler's 0x7fffffff sentinel) gathers a zero row instead of faulting
+    bad = tok.clone()
+    bad[0] = 0x7fffffff
+    if M > 1:
+        bad[M - 1] = -5
+    ops.call("q3asr_embed_norm_x16", ops.ptr(bad), ops.ptr(E), 50, ops.ptr(ho), ops.ptr(w), ops.ptr(x16), M, N, 1e-6, ops.sp())
+    assert not ho[0].any() and not ops.from_x16(x16, M)[0].any() and (M == 1 or not ho[M - 1].any())
+    if M > 2:
+        assert torch.equal(ho[1:M - 1], E[tok[1:M - 1].long()])
 
 
 @pytest.mark.parametrize("B,poss,S,Lmax", [(1, [0], 1, 576), (3, [5, 127, 200], 4, 576), (2, [408, 535], 2, 576),

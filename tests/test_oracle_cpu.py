@@ -156,6 +156,52 @@ def test_cached_decode_equals_full_context():
     assert torch.isfinite(full).all()
 
 
+def test_fp8_activation_flavour_of_the_decoder_oracle():
+    """configs[4] flavour (oracle/decoder.py, `fp8_rows`): e4m3 x e4m3 projections on the prompt rows.  Checked here:
+    the weight quantiser is idempotent on dequantised weights (the GPU tests hand the oracle q * s), the activation
+    quantiser reproduces the e4m3 grid and its scale rule, rows beyond `fp8_rows` keep the bf16 arithmetic, a W8A8
+    prefill followed by W8A16 cached steps equals ONE teacher-forced pass with fp8_rows = prompt length, and the
+    flavour really is a different arithmetic."""
+    import oracle.decoder as od
+    torch.manual_seed(3)
+    W = (torch.randn(96, 64) * 0.02).to(torch.bfloat16).float()
+    W[5] = 0.0                                                                 # an all-zero row must not divide by zero
+    q, s = od.quantize_weight_rows_e4m3(W)
+    assert q.abs().max() <= 448 and torch.equal(torch.log2(s), torch.log2(s).round())           # power-of-two scales
+    assert torch.equal(q.to(torch.float8_e4m3fn).float(), q)                                     # values on the e4m3 grid
+    w_eff = q * s[:, None]
+    assert torch.equal(w_eff.to(torch.bfloat16).float(), w_eff)                                  # exactly representable in bf16
+    q2, s2 = od.quantize_weight_rows_e4m3(w_eff)
+    assert torch.equal(q2 * s2[:, None], w_eff)                                                  # idempotent in value
+    x = torch.randn(5, 64)
+    x[2] = 0.0
+    x8, sa = od.quantize_act_rows_e4m3(x)
+    assert sa[2] == 1.0 and torch.equal(x8[2], torch.zeros(64))
+    live = [0, 1, 3, 4]
+    assert torch.allclose(sa[live] * 448, x[live].abs().amax(-1), rtol=1e-6) and torch.all(x8.abs().amax(-1)[live] == 448)
+    assert (x8 * sa[:, None] - x).abs().max() <= x.abs().max() / 16 + 1e-6                       # 3 mantissa bits: 2^-4 relative
+
+    dec = _tiny_decoder()
+    dec.W = {k: (od.quantize_weight_rows_e4m3(v)[0] * od.quantize_weight_rows_e4m3(v)[1][:, None]
+                 if k.endswith("_proj.weight") or k == "embed_tokens.weight" else v) for k, v in dec.W.items()}
+    ids = [5, 17, 300, 42, 7, 99, 3, 250]
+    plain = dec.forward(dec.embed(ids), last_only=False)
+    dec.reset()
+    f8 = dec.forward(dec.embed(ids), last_only=False, fp8_rows=len(ids))
+    assert torch.isfinite(f8).all() and not torch.equal(f8, plain)
+    assert (f8 - plain).abs().max() < 0.25 * plain.abs().max()                # a perturbation, not another function
+    dec.reset()
+    mixed = dec.forward(dec.embed(ids), last_only=False, fp8_rows=5)          # prompt = 5 rows, 3 teacher-forced tokens
+    dec.reset()
+    pre = dec.forward(dec.embed(ids[:5]), last_only=False, fp8_rows=5)
+    assert torch.equal(pre, mixed[:5])                                         # per-token quantisation: causal rows cannot see later ones
+    for i in range(5, 8):
+        step = dec.forward(dec.embed(ids[i:i + 1]))
+        assert torch.allclose(step[-1], mixed[i], atol=1e-5)                  # cached W8A16 step == row i of the one-pass form
+    dec.reset()
+    assert torch.equal(dec.forward(dec.embed(ids), last_only=False, fp8_rows=0), plain)
+
+
 def test_prepare_inputs_semantics():
     """reference test_generate.py:63-124."""
     E = torch.arange(20 * 4, dtype=torch.float32).reshape(20, 4)

@@ -36,6 +36,27 @@ def test_nan_logits_never_yield_an_out_of_range_token(dev):
     assert 0 <= sample(x, temperature=0.0) < 4096
 
 
+def test_nan_logits_raise_from_the_generation_loop(dev):
+    """The device-side error flag: a row whose logits have no maximum records token 0, stops with finished = Q3ASR_ROW_FAILED
+    (include/q3asr.h), and the host raises when it reads the flag -- a NaN row never decodes on as token 0."""
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
+    from qwen3_asr_mlx_amd._lib import Q3AsrError
+    from signals import signal
+    cfg = synth.small_config()
+    state = synth.random_state(cfg, seed=4, bias_std=0.02, norm_jitter=0.1)
+    state["model.norm.weight"] = torch.full_like(state["model.norm.weight"], float("nan"))      # every logit NaN
+    model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev)
+    clips = [signal("speechlike", 16000, seed=5), signal("speechlike", 24000, seed=6)]
+    with pytest.raises(Q3AsrError, match="non-finite logits"):
+        model.generate_tokens(clips, [8, 8], "English")
+    with pytest.raises(Q3AsrError, match="non-finite logits"):
+        model.transcribe(clips[0], max_tokens=8)
+    model.use_graph = False
+    with pytest.raises(Q3AsrError, match="non-finite logits"):
+        model.generate_tokens(clips, [8, 8], "English")
+
+
 def test_temperature_sampling_is_stochastic(dev):
     from qwen3_asr_mlx_amd import sample
     logits = torch.ones(1, 512)

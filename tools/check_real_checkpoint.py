@@ -4,7 +4,8 @@ have: a local copy of mlx-community/Qwen3-ASR-1.7B-bf16 (config.json, model.safe
 JSON captured on a Mac from the MLX reference:
 
     [{"audio": "a.wav", "language": "en", "tokens": [ids...], "text": "...",
-      "first_logits_top5": [[id, value], ...]}, ...]
+      "first_logits_top5": [[id, value], ...], "max_tokens": 64}, ...]        (max_tokens optional: the budget the
+                                                                               capture ran with; default = transcribe()'s)
 
     python tools/check_real_checkpoint.py /path/to/model_dir reference_outputs.json
 
@@ -71,7 +72,7 @@ def main(argv=None) -> int:
         audio_path = (ref_path.parent / item["audio"]).resolve()
         samples = q.load_audio(audio_path)
         lang = model._resolve_language(item.get("language"))
-        budget = max(256, int(len(samples) / 16000 * 50))
+        budget = int(item["max_tokens"]) if item.get("max_tokens") else max(256, int(len(samples) / 16000 * 50))
         toks = model.generate_tokens([samples], [budget], lang, repetition_penalty=1.2)[0]
         want = item["tokens"]
         n_same = next((i for i, (a, b) in enumerate(zip(toks, want)) if a != b), min(len(toks), len(want)))

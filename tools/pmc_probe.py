@@ -11,6 +11,10 @@ threads, no side streams, no graph capture unless asked for.  Runs, eagerly, on 
   graph4   the same with the 4-step graph
   regraph  capture, replay, DESTROY the graph, capture again, replay (what bench.py's stage leg does to a workspace that
            already holds a graph)
+  finite   one eager batch-32 decode step with every launch followed by a synchronise and a finiteness check of the
+           buffers it may have written (slab poisoned with NaN first, so a read of an unwritten slab element shows too);
+           names the first launch that leaves a non-finite value.  Every mode ends with a check of the device-side error
+           flag (finished == Q3ASR_ROW_FAILED) and of the last logits.
 
 Usage: python3 tools/pmc_probe.py decode,encoder [--batch 32] [--seconds 30]
 Writes gpurun_out/pmc_probe_meta.json: sha-256 (first 16 hex) of the library that ran, and what ran."""
@@ -78,14 +82,61 @@ if "decode" in what:
         dec.gemm_only_step(ws)
     torch.cuda.synchronize()
     say("decode GEMMs done")
-if what & {"prefill", "step", "graph", "graph4", "regraph"}:
+def check_state(ws, where):
+    fin = ws.finished.tolist()
+    bad_rows = [b for b, f in enumerate(fin) if f == 2]
+    finite = bool(torch.isfinite(ws.logits.float()).all())
+    say(f"{where}: rows with the device error flag {bad_rows}; logits finite {finite}; tokens in range "
+        f"{bool(((ws.cur_tok >= 0) & (ws.cur_tok < cfg.text_decoder.vocab_size)).all())}")
+    if bad_rows or not finite:
+        raise SystemExit(f"{where}: non-finite logits (rows {bad_rows})")
+
+
+def finite_step(ws, cache):
+    """One eager decode step, every launch checked."""
+    watched = {"slab": ws.slab, "h": ws.h, "x16": ws.x16, "att16": ws.att16, "act16": ws.act16, "logits": ws.logits}
+    ws.slab.fill_(float("nan"))                                  # an element read before it is written shows up downstream
+    torch.cuda.synchronize()
+    real = _lib.call
+    seen = {"n": 0, "first": None}
+
+    def checked(name, *args):
+        real(name, *args)
+        torch.cuda.synchronize()
+        seen["n"] += 1
+        if seen["first"] is not None or not name.startswith("q3asr_") or name.startswith("q3asr_graph"):
+            return
+        for k, t in watched.items():
+            if k == "slab":
+                continue                                         # holds the poison wherever the last GEMM did not write
+            if not bool(torch.isfinite(t.float()).all()):
+                seen["first"] = (seen["n"], name, k)
+                say(f"launch #{seen['n']} {name}: first non-finite value in {k}")
+                return
+    _lib.call = checked
+    import qwen3_asr_mlx_amd.ops as ops_mod
+    ops_mod.call = checked
+    try:
+        dec.decode_step(ws, cache, sampling)
+    finally:
+        _lib.call = real
+        ops_mod.call = real
+    say(f"finite: {seen['n']} launches checked, first non-finite: {seen['first']}")
+    return seen["first"]
+
+
+if what & {"prefill", "step", "graph", "graph4", "regraph", "finite"}:
     ws, cache = prefilled(B)
     say("prefill done")
+    if "finite" in what:
+        if finite_step(ws, cache) is not None:
+            raise SystemExit("finite: a launch left a non-finite value")
     if "step" in what:
         for _ in range(2):
             dec.decode_step(ws, cache, sampling)
         torch.cuda.synchronize()
         say("eager decode steps done")
+        check_state(ws, "step")
     for name, steps in (("graph", 1), ("graph4", dec.MULTI_STEPS)):
         if name in what:
             side = torch.cuda.Stream(device=dev)
@@ -98,6 +149,7 @@ if what & {"prefill", "step", "graph", "graph4", "regraph"}:
                 side.synchronize()
                 _lib.call("q3asr_graph_destroy", g)
             say(f"{name}: captured and replayed")
+            check_state(ws, name)
     if "regraph" in what:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
@@ -110,12 +162,14 @@ if what & {"prefill", "step", "graph", "graph4", "regraph"}:
                 _lib.call("q3asr_graph_destroy", g)               # destroyed while its launches may still be in flight
             side.synchronize()
         say("regraph: capture / replay / destroy x3 done")
+        check_state(ws, "regraph")
 if "batch1" in what:
     ws1, cache1 = prefilled(1)
     for _ in range(4):
         dec.decode_step(ws1, cache1, sampling)
     torch.cuda.synchronize()
     say("batch-1 eager steps (fused residual+norm GEMM) done")
+    check_state(ws1, "batch1")
 out = ROOT / "gpurun_out"
 out.mkdir(exist_ok=True)
 (out / "pmc_probe_meta.json").write_text(json.dumps({
