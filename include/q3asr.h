@@ -198,7 +198,9 @@ int q3asr_attn_decode(const void* q, const void* k_cache, const void* v_cache, c
 int q3asr_sample_step(const void* logits, int64_t ld, int B, int V, int32_t* out_tokens, int max_out,
                       int32_t* n_gen, int32_t* finished, int32_t* cur_tok, int32_t* pos, const int32_t* max_new,
                       float temperature, float top_p, int top_k, float penalty, int ctx, uint64_t seed,
-                      int eos0, int eos1, void* stream);
+                      int eos0, int eos1, int row_base, void* stream);
+/* row_base: index of this launch's row 0 inside its request -- the random draw of a row is keyed by (seed, token index,
+ * row_base + b), so a request decoded as two half-batches draws what the whole batch would. */
 
 /* ---- hipGraph capture of the decode step; HIP events on an explicit stream -------------------- */
 int q3asr_graph_begin(void* stream);

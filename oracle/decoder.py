@@ -75,6 +75,7 @@ class DecoderOracle:
         self.n_layers = 1 + max(int(k.split(".")[1]) for k in W if k.startswith("layers."))
         self.gpu_rounding = gpu_rounding
         self._w8 = {}                            # name -> (e4m3 values as float32, per-row scale), built on first use
+        self.perturb = 0.0                       # test aid: relative Gaussian noise on every projection before its rounding
         self.reset()
 
     def reset(self):
@@ -94,9 +95,12 @@ class DecoderOracle:
             q, s = self._w8[name]
             x8, sa = quantize_act_rows_e4m3(x[:n8])
             y[:n8] = (x8 @ q.T) * (s[None, :] * sa[:, None])
+        if self.perturb:                         # what a different fp32 summation order / exp implementation does, scaled up
+            y = y * (1.0 + self.perturb * torch.randn(y.shape))
         return y
 
-    def forward(self, h: torch.Tensor, last_only: bool = True, keep_from: int = None, fp8_rows: int = 0) -> torch.Tensor:
+    def forward(self, h: torch.Tensor, last_only: bool = True, keep_from: int = None, fp8_rows: int = 0,
+                return_hidden: bool = False) -> torch.Tensor:
         """h (T, hidden) bf16-valued float32; appends to the cache at
         self.offset and advances it.  Returns bf16-valued logits (T or 1, V)
         (decoder.py:243-253; the reference computes every position, only the
@@ -140,6 +144,8 @@ class DecoderOracle:
             act = bf(gt * torch.sigmoid(gt) * up)
             h = bf(h + bf(self._lin(act, p + "mlp.down_proj.weight", n8)))
         self.offset += T
+        if return_hidden:                       # the residual stream after the last layer, before the final norm (test aid)
+            return h
         if keep_from is not None:               # teacher-forced checks: logits of rows keep_from.. only
             h = h[keep_from:]
         elif last_only:

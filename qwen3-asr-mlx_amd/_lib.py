@@ -48,7 +48,7 @@ _SIGS = {
     "q3asr_slab_residual_rmsnorm": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_slab_swiglu": [_vp, _i, _i64, _vp, _i, _i, _vp],
     "q3asr_attn_decode": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
-    "q3asr_sample_step": [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _u64, _i, _i, _vp],
+    "q3asr_sample_step": [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _u64, _i, _i, _i, _vp],
     "q3asr_graph_begin": [_vp],
     "q3asr_graph_end": [_vp, C.POINTER(_vp)],
     "q3asr_graph_launch": [_vp, _vp],

@@ -41,6 +41,7 @@ struct SampleParams {
     float temperature, top_p, penalty; int top_k; int ctx;
     unsigned long long seed;
     int eos0, eos1;
+    int row_base;             // global index of row 0 in its request: the draw of a row does not depend on how the batch was cut
 };
 
 __device__ __forceinline__ unsigned key16(float x) {          // order-preserving 16-bit key of a bf16-valued float
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_draw_kernel(const SamplePa
     const bool use_k = p.top_k > 0 && p.top_k < p.V, use_p = p.top_p < 1.0f;
     int total_c = 0;
     const int pre_c = use_k ? block_excl_scan(cnt[0] + cnt[1] + cnt[2] + cnt[3], sh.red_i, total_c) : 0;
-    const float u01 = philox_uniform(p.seed, (unsigned)n, (unsigned)b);
+    const float u01 = philox_uniform(p.seed, (unsigned)n, (unsigned)(b + p.row_base));
 
     // Three resolutions of a coarse bin to exact keys, in order: 0 = top-k threshold (generate.py:134-150, ties kept),
     // 1 = nucleus crossing (generate.py:152-163: key fk, of which the first keep_eq logits in index order stay),
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_draw_kernel(const SamplePa
 extern "C" int q3asr_sample_step(const void* logits, int64_t ld, int B, int V, int32_t* out_tokens, int max_out,
                                  int32_t* n_gen, int32_t* finished, int32_t* cur_tok, int32_t* pos, const int32_t* max_new,
                                  float temperature, float top_p, int top_k, float penalty, int ctx, uint64_t seed,
-                                 int eos0, int eos1, void* stream) {
+                                 int eos0, int eos1, int row_base, void* stream) {
     Q3_REQUIRE(logits && out_tokens && n_gen && finished && cur_tok && pos && max_new, "sample_step: null pointer");
     Q3_REQUIRE(B > 0 && V > 0 && V % 32 == 0 && ld % 8 == 0 && ld >= V, "sample_step: V=%d must be a multiple of 32, ld aligned", V);
     Q3_REQUIRE(V <= 64 * 8 * SMP_THREADS, "sample_step: V=%d too large (at most %d)", V, 64 * 8 * SMP_THREADS);
@@ -573,7 +574,7 @@ extern "C" int q3asr_sample_step(const void* logits, int64_t ld, int B, int V, i
     p.logits = (const bf16*)logits; p.ld = ld; p.V = V; p.out_tokens = out_tokens; p.max_out = max_out;
     p.n_gen = n_gen; p.finished = finished; p.cur_tok = cur_tok; p.pos = pos; p.max_new = max_new;
     p.temperature = temperature; p.top_p = top_p; p.penalty = penalty; p.top_k = top_k; p.ctx = ctx; p.seed = seed;
-    p.eos0 = eos0; p.eos1 = eos1;
+    p.eos0 = eos0; p.eos1 = eos1; p.row_base = row_base;
     const size_t bitmap = (size_t)((V / 8 + 15) / 16) * 16;
     if (temperature == 0.0f) {
         hipLaunchKernelGGL(sample_greedy_kernel, dim3(B), dim3(SMP_THREADS), bitmap, (hipStream_t)stream, p);

@@ -87,9 +87,14 @@ class _Embedding:
 
 
 class DecodeWorkspace:
-    """Device state of one decode batch; pointers are stable so one hipGraph serves every step."""
+    """Device state of one decode batch; pointers are stable so one hipGraph serves every step.
+    `parent` / `row0`: rows row0 .. row0+B-1 of another workspace's per-sequence state (tokens, positions, counters, flags,
+    output ids, logits) seen as a batch of their own with private activation buffers; `row_base` keys the sampler's draws by
+    the request-wide row index, so a row draws the same token whichever way its batch is cut (tools/ab_chains.py decodes a
+    batch as two launch chains that way: measured slower)."""
 
-    def __init__(self, cfg: TextDecoderConfig, B: int, max_out: int, device, fp8: bool = False):
+    def __init__(self, cfg: TextDecoderConfig, B: int, max_out: int, device, fp8: bool = False, parent: "DecodeWorkspace" = None,
+                 row0: int = 0):
         import torch
         i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=device)          # noqa: E731
         bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=device)        # noqa: E731
@@ -97,11 +102,20 @@ class DecodeWorkspace:
         qd = cfg.num_attention_heads * cfg.head_dim
         qkvd = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim
         self.B, self.max_out = B, max_out
-        self.cur_tok, self.pos, self.n_gen, self.finished, self.max_new = i32(B), i32(B), i32(B), i32(B), i32(B)
+        self.parent, self.row_base = parent, int(row0)       # row_base keys the sampler's draws by the request-wide row index
+        if parent is None:
+            self.cur_tok, self.pos, self.n_gen, self.finished, self.max_new = i32(B), i32(B), i32(B), i32(B), i32(B)
+            self.out_tokens = i32(B, max_out)
+            self.logits = bf(B, cfg.vocab_size)
+        else:
+            if not (0 <= row0 and row0 + B <= parent.B and max_out == parent.max_out):
+                raise ValueError("chain workspace: rows outside the parent")
+            r = slice(row0, row0 + B)
+            self.cur_tok, self.pos, self.n_gen, self.finished, self.max_new = (parent.cur_tok[r], parent.pos[r], parent.n_gen[r],
+                                                                               parent.finished[r], parent.max_new[r])
+            self.out_tokens, self.logits = parent.out_tokens[r], parent.logits[r]
         self.row_b = torch.arange(B, dtype=torch.int32, device=device)
-        self.out_tokens = i32(B, max_out)
         self.h, self.x, self.q, self.att, self.act = bf(B, H), bf(B, H), bf(B, qd), bf(B, qd), bf(B, I)
-        self.logits = bf(B, cfg.vocab_size)
         self.cfg = cfg
         self.MT = ops.mt_of(B)
         rows = 16 * self.MT
@@ -257,8 +271,16 @@ class TextDecoder:
             plans[key] = pl
         return pl
 
-    def _layers_prefill(self, h, cache: KVCache, seq_lens: Sequence[int], slots: Optional[Sequence[int]] = None):
-        """h bf16 [M][H] (packed rows of all sequences, positions start at 0) -> updated in place."""
+    def _layers_prefill(self, h, cache: KVCache, seq_lens: Sequence[int], slots: Optional[Sequence[int]] = None, trace: Optional[list] = None):
+        """h bf16 [M][H] (packed rows of all sequences, positions start at 0) -> updated in place.
+        `trace` (tests): a list that receives, per layer, a dict of clones of every intermediate the layer hands from one
+        kernel to the next, so that each stage can be checked against the oracle from the inputs the GPU itself saw."""
+        def keep(li, **kw):
+            if trace is not None:
+                while len(trace) <= li:
+                    trace.append({})
+                trace[li].update({k: v.clone() for k, v in kw.items()})
+
         import torch
         cfg, w, dev = self.config, self.w, self.device
         if slots is not None:
@@ -287,8 +309,10 @@ class TextDecoder:
             c8 = torch.empty((M, I), dtype=u8, device=dev)
             sx, sa_, sc = (torch.empty((M,), dtype=f32, device=dev) for _ in range(3))
             for li, L in enumerate(w["layers"]):
+                keep(li, h_in=h)
                 ops.rmsnorm_fp8(h, L["ln1"], x8, sx, M, H, eps)
                 ops.gemm_fp8(x8, sx, L["wqkv"], L["wqkv_s"], M, qkvd, H, qkv)
+                keep(li, x8_1=x8, sx_1=sx, qkv=qkv)
                 ops.call("q3asr_qk_norm_rope_kv", ops.ptr(qkv), 0, qkvd, 0, 0, ops.ptr(pl["row_b"]), ops.ptr(pl["row_pos"]),
                          ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(q), ops.ptr(cache.k[li]),
                          ops.ptr(cache.v[li]), M, nh, nkv, hd, Lmax, ops.sp())
@@ -296,23 +320,31 @@ class TextDecoder:
                              pl["seg_start"], pl["seg_len"], len(seq_lens), pl["max_len"], nh, nkv, hd, True, scale)
                 ops.quantize_rows_fp8(att, a8, sa_, M, qd)
                 ops.gemm_fp8(a8, sa_, L["wo"], L["wo_s"], M, H, qd, h, res=h)
+                keep(li, q=q, att=att, a8=a8, sa=sa_, h_mid=h)
                 ops.rmsnorm_fp8(h, L["ln2"], x8, sx, M, H, eps)
                 ops.gemm_fp8(x8, sx, L["wgu"], L["wgu_s"], M, 2 * I, H, act, act=2)
                 ops.quantize_rows_fp8(act, c8, sc, M, I)
+                keep(li, x8_2=x8, sx_2=sx, act=act, c8=c8, sc=sc)
                 ops.gemm_fp8(c8, sc, L["wdown"], L["wdown_s"], M, H, I, h, res=h)
+                keep(li, h_out=h)
             return pl
         for li, L in enumerate(w["layers"]):
+            keep(li, h_in=h)
             ops.rmsnorm(h, L["ln1"], x, M, H, eps)
             ops.gemm(x, L["wqkv"], M, qkvd, H, qkv)
+            keep(li, x_1=x, qkv=qkv)
             ops.call("q3asr_qk_norm_rope_kv", ops.ptr(qkv), 0, qkvd, 0, 0, ops.ptr(pl["row_b"]), ops.ptr(pl["row_pos"]),
                      ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(q), ops.ptr(cache.k[li]),
                      ops.ptr(cache.v[li]), M, nh, nkv, hd, Lmax, ops.sp())
             ops.attn_fwd(ops.ptr(q), qd, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), pl["kv_off"], Lmax * hd, hd, att, qd,
                          pl["seg_start"], pl["seg_len"], len(seq_lens), pl["max_len"], nh, nkv, hd, True, scale)
             ops.gemm(att, L["wo"], M, H, qd, h, res=h, res_kind=2, ldres=H)
+            keep(li, q=q, att=att, h_mid=h)
             ops.rmsnorm(h, L["ln2"], x, M, H, eps)
             ops.gemm(x, L["wgu"], M, 2 * I, H, act, act=2)
+            keep(li, x_2=x, act=act)
             ops.gemm(act, L["wdown"], M, H, I, h, res=h, res_kind=2, ldres=H)
+            keep(li, h_out=h)
         return pl
 
     def prefill(self, embeds, seq_lens: Sequence[int], cache: KVCache, logits_out=None, slots: Optional[Sequence[int]] = None):
@@ -505,7 +537,8 @@ class TextDecoder:
         ops.call("q3asr_sample_step", ops.ptr(logits), logits.stride(0), ws.B, self.config.vocab_size, ops.ptr(ws.out_tokens),
                  ws.max_out, ops.ptr(ws.n_gen), ops.ptr(ws.finished), ops.ptr(ws.cur_tok), ops.ptr(ws.pos), ops.ptr(ws.max_new),
                  float(s["temperature"]), float(s["top_p"]), int(s["top_k"]), float(s["repetition_penalty"]),
-                 int(s["repetition_context_size"]), int(s.get("seed", 0)), ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID, ops.sp())
+                 int(s["repetition_context_size"]), int(s.get("seed", 0)), ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID, int(getattr(ws, "row_base", 0)),
+                 ops.sp())
 
     def sample_rows(self, ws: DecodeWorkspace, logits_row, row: int, s: dict) -> None:
         """sample_step for ONE row of the workspace from a separate logits vector (a sequence admitted into a running batch
@@ -515,7 +548,7 @@ class TextDecoder:
                  ws.max_out, ops.ptr(ws.n_gen[row:]), ops.ptr(ws.finished[row:]), ops.ptr(ws.cur_tok[row:]), ops.ptr(ws.pos[row:]),
                  ops.ptr(ws.max_new[row:]), float(s["temperature"]), float(s["top_p"]), int(s["top_k"]),
                  float(s["repetition_penalty"]), int(s["repetition_context_size"]), int(s.get("seed", 0)) + 0x9E3779B97F4A7C15 * (row + 1) & 0x7FFFFFFFFFFFFFFF,
-                 ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID, ops.sp())
+                 ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID, 0, ops.sp())
 
     # ------------------------------------------------------------------ hipGraph
     MULTI_STEPS = 4     # decode steps per launch of the second graph (a replay boundary costs ~8 us of idle GPU)

@@ -83,7 +83,7 @@ def sample(logits, temperature: float = 0.0, top_p: float = 1.0, top_k: int = 0,
         seed = (torch.initial_seed() * 1000003 + _sample_calls) & 0xFFFFFFFFFFFFFFFF
     ops.call("q3asr_sample_step", ops.ptr(buf), Vp, 1, Vp, ops.ptr(out_tokens), n + 1, ops.ptr(n_gen), ops.ptr(fin),
              ops.ptr(cur), ops.ptr(pos), ops.ptr(mx), float(temperature), float(top_p), int(top_k),
-             float(repetition_penalty), max(n, 1), int(seed), -1, -1, ops.sp())
+             float(repetition_penalty), max(n, 1), int(seed), -1, -1, 0, ops.sp())
     return int(cur.item())
 
 
@@ -427,10 +427,10 @@ def generate_continuous(decoder: TextDecoder, feats: Sequence, prompts: Sequence
 _streams: dict = {}
 
 
-def _side_stream(dev):
+def _side_stream(dev, chain: int = 0):
     import torch
     from .decoder import current_lane
-    key = (str(dev), current_lane())
+    key = (str(dev), current_lane(), chain)
     s = _streams.get(key)
     if s is None:
         s = _streams[key] = torch.cuda.Stream(device=dev)

@@ -27,6 +27,15 @@ ROOT = Path(__file__).resolve().parent.parent
 # Logit tolerance in bf16 ulps OF THE TOP LOGIT (logits are bf16, decoder.py:252: one ulp is the resolution of the
 # reference's own output).  2 ulps for the 2-layer config; 4 ulps after 28 layers of bf16 re-rounding at the 1.7B shapes.
 ULPS_SMALL, ULPS_FULL = 2.0, 4.0
+# weight_dtype="fp8": per-token e4m3 quantisation is discontinuous -- a one-bf16-ulp difference in an operand becomes a whole
+# e4m3 step (2^-4 relative) when it crosses a rounding boundary, and a one-ulp difference in a row's largest element moves the
+# row's whole grid.  The e4m3 oracle flavour itself moves 3-5 x as far as the bf16 flavour under the same sub-ulp perturbation
+# of its projections (tests/test_oracle_cpu.py::test_fp8_flavour_amplifies_perturbations pins that factor), so two correct
+# implementations of the W8A8 prefill agree to a multiple of the bf16 bar, not to the bf16 bar; the multiple grows with depth
+# (measured on the CPU oracle alone: 3.2-4.8 x at 2 layers, 6-7 x at the 1.7B shapes' 28 layers, where two faithful runs keep
+# only ~40 % of their quantisation noise in common).  What pins the arithmetic itself is bit-exact and depth-free: the
+# quantiser and the fp8 GEMM in tests/test_kernels_gpu.py, and one whole layer against the oracle below.
+FP8_AMPLIFICATION = {"small": 4.0, "full": 8.0}
 # absolute bound on the last-position logits at the 1.7B shapes (|logit| <= ~5 with N(0, 0.02^2) weights)
 FULL_LOGIT_ATOL = 0.125
 
@@ -362,9 +371,11 @@ def test_fp8_mfma_prefill_matches_the_e4m3_oracle(dev, which):
     """weight_dtype="fp8": prefill projections fp8 x fp8 on the fp8 MFMA with per-token activation scales (decode steps keep
     bf16 activations).  Checked STRICTLY against the oracle flavour that performs the same quantisations (e4m3 weights per
     output row, e4m3 activations per token at the RMSNorm / attention / SwiGLU outputs of the prompt rows): last-position
-    logits within ULPS bf16 ulps of the top logit and margin-aware greedy tokens, every decisive step exact -- the bar of the
-    bf16 model.  The weight-only variant "fp8w" is held to the same bar against the dequantised-weight oracle, and what the
-    activation quantisation costs against THAT oracle is recorded beside it."""
+    logits and margin-aware greedy tokens, every decisive step exact, every other step inside the tolerance.  The weight-only
+    variant "fp8w" is held to the bf16 model's bar against the dequantised-weight oracle; "fp8" to FP8_AMPLIFICATION times that
+    bar (the discontinuity of e4m3 rounding, see the constant), with the counts at the bf16 bar recorded beside it; and each
+    weight-only mode must sit closer to its own oracle flavour than to the other one (at 28 layers two W8A8 runs share too
+    little of their quantisation noise for that to hold the other way round: recorded)."""
     import oracle
     import qwen3_asr_mlx_amd as q
     from qwen3_asr_mlx_amd import ops, synth
@@ -387,6 +398,7 @@ def test_fp8_mfma_prefill_matches_the_e4m3_oracle(dev, which):
     res = {}
     for mode in ("fp8w", "fp8"):
         f8 = mode == "fp8"
+        tol_ulps = ulps * (FP8_AMPLIFICATION[which] if f8 else 1.0)
         model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype=mode)
         got, _ = _gpu_prefill_logits(model, clips[-1])
         f_ref = enc(oracle.log_mel_spectrogram(clips[-1]))
@@ -394,31 +406,185 @@ def test_fp8_mfma_prefill_matches_the_e4m3_oracle(dev, which):
         dec.reset()
         ref = dec.forward(emb, fp8_rows=emb.shape[0] if f8 else 0)[-1]
         dec.reset()
-        ref_bf16_act = dec.forward(emb)[-1]                                   # dequantised weights, bf16 activations
+        ref_other = dec.forward(emb, fp8_rows=0 if f8 else emb.shape[0])[-1]    # the OTHER flavour: the GPU mode must sit closer to its own
         toks_all = model.generate_tokens(clips, [128] * len(clips), "English", repetition_penalty=1.2)
         tot = {"n": 0, "exact": 0, "decisive": 0, "decisive_exact": 0, "max_gap_in_tol_units": 0.0}
+        at_bf16_bar = {"decisive": 0, "decisive_exact": 0, "max_gap_in_tol_units": 0.0}
         for x, toks in zip(clips, toks_all):
             lg = _teacher_forced_logits(dec, enc(oracle.log_mel_spectrogram(x)), toks, fp8_prompt=f8)
-            st = _margin_check(lg, toks, 1.2, ulps, strict=True)
+            st = _margin_check(lg, toks, 1.2, tol_ulps, strict=False)
             for k, v in st.items():
                 tot[k] = max(tot[k], v) if k.startswith("max") else tot[k] + v
+            if f8:                                                             # recorded: the same steps held to the bf16 model's bar
+                sb = _margin_check(lg, toks, 1.2, ulps, strict=False)
+                for k in at_bf16_bar:
+                    at_bf16_bar[k] = max(at_bf16_bar[k], sb[k]) if k.startswith("max") else at_bf16_bar[k] + sb[k]
         top = float(ref.abs().max())
         res[mode] = {"logit_max_diff": round(float((got - ref).abs().max()), 4), "logit_mean_diff": round(float((got - ref).abs().mean()), 5),
-                     "logit_absmax": round(top, 3), "logit_tol": ulps * _ulp_bf16(top),
+                     "logit_absmax": round(top, 3), "logit_tol": tol_ulps * _ulp_bf16(top),
                      "same_argmax": bool(int(got.argmax()) == int(ref.argmax())),
                      "top1_margin": round(float(torch.topk(ref, 2).values.diff().abs()), 4),
-                     "vs_bf16_activation_oracle_max": round(float((got - ref_bf16_act).abs().max()), 4),
-                     "vs_bf16_activation_oracle_mean": round(float((got - ref_bf16_act).abs().mean()), 5),
+                     "vs_other_flavour_max": round(float((got - ref_other).abs().max()), 4),
+                     "vs_other_flavour_mean": round(float((got - ref_other).abs().mean()), 5),
                      "tokens": tot["n"], "exact_rate": round(tot["exact"] / tot["n"], 4), "decisive": tot["decisive"],
-                     "decisive_exact": tot["decisive_exact"], "max_gap_in_tol_units": round(tot["max_gap_in_tol_units"], 2), "tol_ulps": ulps}
+                     "decisive_exact": tot["decisive_exact"], "max_gap_in_tol_units": round(tot["max_gap_in_tol_units"], 2), "tol_ulps": tol_ulps}
+        if f8:
+            res[mode]["at_the_bf16_bar"] = {**at_bf16_bar, "max_gap_in_tol_units": round(at_bf16_bar["max_gap_in_tol_units"], 2), "tol_ulps": ulps}
         del model
     _record(f"fp8_mfma_prefill_{which}", res)
     for mode, r in res.items():
         assert r["logit_max_diff"] <= r["logit_tol"], (mode, r)
         assert r["same_argmax"] or r["top1_margin"] <= 2 * r["logit_tol"], (mode, r)
-        assert r["decisive_exact"] == r["decisive"] and r["decisive"] >= (300 if which == "small" else 64), (mode, r)
-    # the flavour is not vacuous: against the bf16-activation oracle the W8A8 logits sit measurably further away
-    assert res["fp8"]["vs_bf16_activation_oracle_mean"] > 2 * res["fp8"]["logit_mean_diff"], res["fp8"]
+        assert r["decisive_exact"] == r["decisive"] and r["max_gap_in_tol_units"] <= 1.0, (mode, r)   # margin-aware, strict
+    f8r, wr = res["fp8"], res["fp8w"]
+    assert wr["decisive"] >= (300 if which == "small" else 64), res
+    assert wr["logit_mean_diff"] < wr["vs_other_flavour_mean"], res            # weight-only sits with the bf16-activation oracle ...
+    assert f8r["logit_mean_diff"] <= 8.0 * wr["logit_mean_diff"], res          # ... W8A8 within the amplification of ITS oracle (CPU: 3-7 x)
+    b = f8r["at_the_bf16_bar"]                                                  # and, held to the bf16 model's bar, the decisive steps still agree
+    assert b["decisive"] >= (300 if which == "small" else 64) and b["decisive_exact"] >= b["decisive"] - (0 if which == "small" else 2), res
+
+
+def _stage_cmp(got, ref):
+    """Element-wise agreement of one kernel stage with the oracle run on the SAME inputs.  One ulp = 2^-8 of max(|ref element|,
+    rms of its row): an element much smaller than its row's scale is not held to its own tiny ulp (its error is set by the
+    terms that cancelled into it)."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    d = (got - ref).abs()
+    rms = ref.pow(2).mean(-1, keepdim=True).sqrt()
+    ulp = torch.exp2(torch.floor(torch.log2(torch.maximum(ref.abs(), rms).clamp_min(1e-30))) - 7)
+    return {"equal": round(float((d == 0).float().mean()), 5), "within_1_ulp": round(float((d <= ulp).float().mean()), 5),
+            "max_ulps": round(float((d / ulp).max()), 2)}
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_one_full_size_layer_stage_by_stage_from_identical_inputs(dev, mode):
+    """ONE decoder layer at the 1.7B dimensions (hidden 2,048, 16/8 heads, MLP 6,144) over 408 packed prompt rows, checked
+    kernel stage by kernel stage: every stage's output on the GPU against the oracle's arithmetic applied to the inputs the
+    GPU ITSELF fed that stage (decoder._layers_prefill(trace=...)).  No noise is carried from stage to stage, so nothing is
+    amplified: a slip anywhere in the chain -- which operand is quantised and with which row's scale, e4m3 rounding, where
+    the residual enters, the SwiGLU pairing -- shows at its stage, in bf16 and in fp8 mode alike.  (End to end, the same
+    layer differs from the oracle in 46 % of its elements in bf16 mode and 92 % in fp8 mode, by up to 5 and 40 ulps: e4m3
+    rounding amplifies the one-ulp differences the attention hands it, which is why the full-depth fp8 test above has a
+    wider bar -- measured here, recorded as `end_to_end`.)
+    Bars: quantised bytes and per-token scales identical (>= 99.9 %; measured 100 %); norms and RoPE >= 99.9 % identical, never
+    further than 1 ulp; GEMM stages (+ residual) >= 99.9 % identical in bf16 mode and >= 98 % in fp8 mode, >= 99.9 % within
+    one ulp, never further than 2; SwiGLU >= 97 % identical, never further than 4; attention (online softmax against a
+    two-pass softmax) >= 75 % identical, >= 99.9 % within one ulp, never further than 2."""
+    import oracle
+    import oracle.decoder as od
+    from qwen3_asr_mlx_amd import synth
+    from qwen3_asr_mlx_amd.config import ModelConfig, TextDecoderConfig
+    from qwen3_asr_mlx_amd.decoder import KVCache, TextDecoder
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    full = ModelConfig()
+    tcfg = TextDecoderConfig(**{**full.text_decoder.__dict__, "num_hidden_layers": 1, "vocab_size": 4096})
+    cfg = ModelConfig(audio_encoder=synth.small_config().audio_encoder, text_decoder=tcfg)
+    state = synth.random_state(cfg, seed=21, device=dev, norm_jitter=0.1)
+    W = {k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}
+    f8 = mode == "fp8"
+    dec = TextDecoder(tcfg)
+    dec.load_state(W, dev, "fp8" if f8 else "bf16")
+    T, H, I = 408, tcfg.hidden_size, tcfg.intermediate_size
+    nh, nkv, hd, eps = tcfg.num_attention_heads, tcfg.num_key_value_heads, tcfg.head_dim, tcfg.rms_norm_eps
+    g = torch.Generator().manual_seed(5)
+    h0 = (torch.randn(T, H, generator=g) * 0.5).to(torch.bfloat16)
+    h0[7] *= 30.0                                                              # rows of very different scale (per-token scales)
+    h = h0.to(dev).clone()
+    cache = KVCache()
+    cache.ensure(tcfg, 1, 448, dev)
+    trace: list = []
+    dec._layers_prefill(h, cache, [T], trace=trace)
+    tr = {k: v.cpu() for k, v in trace[0].items()}
+    Wf = {k: v.float().cpu() for k, v in W.items()}
+    P = "layers.0."
+    W8 = {k: od.quantize_weight_rows_e4m3(v) for k, v in Wf.items() if k.endswith("_proj.weight")} if f8 else {}
+
+    def lin(x, names, x8=None, sa=None):
+        """bf16-valued outputs of the projections `names` (concatenated): bf16 operands, or e4m3 bytes + per-token scales."""
+        outs = []
+        for n in names:
+            if f8:
+                qw, sw = W8[P + n]
+                outs.append(od.bf((x8 @ qw.T) * (sw[None, :] * sa[:, None])))
+            else:
+                outs.append(od.bf(x @ Wf[P + n].T))
+        return torch.cat(outs, dim=1)
+
+    def e4m3(t):
+        return t.view(torch.float8_e4m3fn).float()
+
+    rec = {}
+
+    def quant_stage(name, src, got8, gots):
+        q8, sc = od.quantize_act_rows_e4m3(src)
+        rec[name] = {"bytes_equal": round(float((e4m3(got8) == q8).float().mean()), 5), "scales_equal": round(float((gots == sc).float().mean()), 5)}
+        return e4m3(got8), gots.float()
+
+    # --- stage 1: input RMSNorm (+ per-token quantisation), then the q/k/v projections
+    x1 = od.rms_norm(tr["h_in"].float(), Wf[P + "input_layernorm.weight"], eps)
+    qkv_names = ["self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight"]
+    if f8:
+        x8, sa = quant_stage("rmsnorm1_quant", x1, tr["x8_1"], tr["sx_1"])
+        rec["qkv"] = _stage_cmp(tr["qkv"], lin(None, qkv_names, x8, sa))
+    else:
+        rec["rmsnorm1"] = _stage_cmp(tr["x_1"], x1)
+        rec["qkv"] = _stage_cmp(tr["qkv"], lin(tr["x_1"].float(), qkv_names))
+    # --- stage 2: QK-norm + RoPE + causal GQA attention, from the GPU's own qkv
+    qkv = tr["qkv"].float()
+    pos = torch.arange(T)
+    qh = od.rope(od.rms_norm(qkv[:, : nh * hd].reshape(T, nh, hd), Wf[P + "self_attn.q_norm.weight"], eps).transpose(0, 1), pos, tcfg.rope_theta)
+    kh = od.rope(od.rms_norm(qkv[:, nh * hd: (nh + nkv) * hd].reshape(T, nkv, hd), Wf[P + "self_attn.k_norm.weight"], eps).transpose(0, 1), pos, tcfg.rope_theta)
+    vh = qkv[:, (nh + nkv) * hd:].reshape(T, nkv, hd).transpose(0, 1)
+    rec["q_norm_rope"] = _stage_cmp(tr["q"], qh.transpose(0, 1).reshape(T, nh * hd))
+    sc_ = (qh @ kh.repeat_interleave(nh // nkv, dim=0).transpose(1, 2)) * hd ** -0.5
+    sc_ = sc_.masked_fill(~(pos[None, :] <= pos[:, None])[None], float("-inf"))
+    pr = torch.exp(sc_ - sc_.max(-1, keepdim=True).values)
+    att = od.bf((od.bf(pr) @ vh.repeat_interleave(nh // nkv, dim=0)) / pr.sum(-1, keepdim=True)).transpose(0, 1).reshape(T, nh * hd)
+    rec["attention"] = _stage_cmp(tr["att"], att)
+    # --- stage 3: o projection + residual, from the GPU's own attention output
+    if f8:
+        a8, sa = quant_stage("attention_quant", tr["att"].float(), tr["a8"], tr["sa"])
+        o = lin(None, ["self_attn.o_proj.weight"], a8, sa)
+    else:
+        o = lin(tr["att"].float(), ["self_attn.o_proj.weight"])
+    rec["o_proj_residual"] = _stage_cmp(tr["h_mid"], od.bf(tr["h_in"].float() + o))
+    # --- stage 4: post-attention RMSNorm, gate/up + SwiGLU, from the GPU's own residual stream
+    x2 = od.rms_norm(tr["h_mid"].float(), Wf[P + "post_attention_layernorm.weight"], eps)
+    if f8:
+        x8, sa = quant_stage("rmsnorm2_quant", x2, tr["x8_2"], tr["sx_2"])
+        gu = lin(None, ["mlp.gate_proj.weight", "mlp.up_proj.weight"], x8, sa)
+    else:
+        rec["rmsnorm2"] = _stage_cmp(tr["x_2"], x2)
+        gu = lin(tr["x_2"].float(), ["mlp.gate_proj.weight", "mlp.up_proj.weight"])
+    gt, up = gu[:, :I], gu[:, I:]
+    rec["gate_up_swiglu"] = _stage_cmp(tr["act"], od.bf(gt * torch.sigmoid(gt) * up))
+    # --- stage 5: down projection + residual, from the GPU's own activation
+    if f8:
+        c8, sc8 = quant_stage("swiglu_quant", tr["act"].float(), tr["c8"], tr["sc"])
+        dn = lin(None, ["mlp.down_proj.weight"], c8, sc8)
+    else:
+        dn = lin(tr["act"].float(), ["mlp.down_proj.weight"])
+    rec["down_proj_residual"] = _stage_cmp(tr["h_out"], od.bf(tr["h_mid"].float() + dn))
+    assert torch.equal(tr["h_out"], h.cpu())
+    # --- and the whole layer end to end against the oracle (recorded: this is what amplification does to it)
+    Wd = {k: (W8[k][0] * W8[k][1][:, None] if k in W8 else v) for k, v in Wf.items()}
+    orc = oracle.DecoderOracle(Wd, nh, nkv, hd, eps, tcfg.rope_theta, gpu_rounding=True)
+    rec["end_to_end"] = _stage_cmp(h.cpu(), orc.forward(h0.float(), fp8_rows=T if f8 else 0, return_hidden=True))
+    _record(f"one_layer_stages_{mode}", rec)
+    gemm_equal = 0.98 if f8 else 0.999          # the fp8 MFMA's accumulation differs from an fp32 dot product in more last bits
+    for name, r in rec.items():
+        if name.endswith("_quant"):
+            assert r["bytes_equal"] >= 0.999 and r["scales_equal"] >= 0.99, (name, r)
+        elif name in ("rmsnorm1", "rmsnorm2", "q_norm_rope"):
+            assert r["equal"] >= 0.999 and r["max_ulps"] <= 1.0, (name, r)
+        elif name in ("qkv", "o_proj_residual", "down_proj_residual"):
+            assert r["equal"] >= gemm_equal and r["within_1_ulp"] >= 0.999 and r["max_ulps"] <= 2.0, (name, r)
+        elif name == "gate_up_swiglu":
+            assert r["equal"] >= 0.97 and r["within_1_ulp"] >= 0.999 and r["max_ulps"] <= 4.0, (name, r)
+        elif name == "attention":
+            assert r["equal"] >= 0.75 and r["within_1_ulp"] >= 0.999 and r["max_ulps"] <= 2.0, (name, r)
+        else:
+            assert name == "end_to_end"
 
 
 # ----------------------------------------------------------------------------- BASELINE.json configs[4] at full size

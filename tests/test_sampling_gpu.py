@@ -150,7 +150,7 @@ def test_bookkeeping_eos_budget_and_finished(dev):
 
     def step(eos0=5, eos1=ENDOFTEXT_TOKEN_ID):
         ops.call("q3asr_sample_step", ops.ptr(logits), V, B, V, ops.ptr(out), 4, ops.ptr(n_gen), ops.ptr(fin), ops.ptr(cur),
-                 ops.ptr(pos), ops.ptr(mx), 0.0, 1.0, 0, 1.0, 100, 0, eos0, eos1, ops.sp())
+                 ops.ptr(pos), ops.ptr(mx), 0.0, 1.0, 0, 1.0, 100, 0, eos0, eos1, 0, ops.sp())
     step()
     assert out[0, 0].item() == 5 and fin[0].item() == 1 and pos[0].item() == 10      # EOS recorded, then stop
     assert out[1, 0].item() == 7 and fin[1].item() == 1                               # budget of 1 reached
@@ -162,7 +162,7 @@ def test_bookkeeping_eos_budget_and_finished(dev):
 # ---------------------------------------------------------------------------------------------------
 # full-vocabulary rows through the C-ABI, many independent draws per launch (row b draws with Philox
 # counter (n_gen, b), so B copies of one row are B independent draws)
-def _draw_many(row_bf16, n_draws, temperature, top_p=1.0, top_k=0, B=64):
+def _draw_many(row_bf16, n_draws, temperature, top_p=1.0, top_k=0, B=64, row_base=0):
     from qwen3_asr_mlx_amd import ops
     dev = row_bf16.device
     V = row_bf16.numel()
@@ -174,9 +174,20 @@ def _draw_many(row_bf16, n_draws, temperature, top_p=1.0, top_k=0, B=64):
         n_gen, fin, cur, pos, mx = i32([0] * B), i32([0] * B), i32([0] * B), i32([0] * B), i32([1] * B)
         ops.call("q3asr_sample_step", ops.ptr(logits), V, B, V, ops.ptr(out_tokens), 1, ops.ptr(n_gen), ops.ptr(fin),
                  ops.ptr(cur), ops.ptr(pos), ops.ptr(mx), float(temperature), float(top_p), int(top_k), 1.0, 1,
-                 1000 + it, -1, -1, ops.sp())
+                 1000 + it, -1, -1, row_base, ops.sp())
         out += cur.tolist()
     return np.array(out[:n_draws])
+
+
+def test_draw_is_keyed_by_the_global_row_index(dev):
+    """row_base: rows 16..31 of a 32-row launch draw exactly what a 16-row launch with row_base = 16 draws (a request decoded
+    as two half-batches samples what the whole batch would)."""
+    torch.manual_seed(3)
+    row = (torch.randn(4096) * 2).to(torch.bfloat16).to(dev)
+    whole = _draw_many(row, 32, 0.9, top_p=0.95, B=32)
+    half = _draw_many(row, 16, 0.9, top_p=0.95, B=16, row_base=16)
+    assert np.array_equal(whole[16:], half) and len(set(whole.tolist())) > 4
+    assert not np.array_equal(whole[:16], half)
 
 
 def _oracle_probs(row_bf16, temperature, top_p, top_k):

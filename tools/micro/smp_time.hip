@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
         hipMemcpy(out, ho, B * max_out * 4, hipMemcpyHostToDevice);
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a);
-        int rc = q3asr_sample_step(d, V, B, V, out, max_out, st, st + B, st + 2 * B, st + 3 * B, st + 4 * B, 0.7f, top_p, top_k, penalty, 100, 5 + it, -1, -1, 0);
+        int rc = q3asr_sample_step(d, V, B, V, out, max_out, st, st + B, st + 2 * B, st + 3 * B, st + 4 * B, 0.7f, top_p, top_k, penalty, 100, 5 + it, -1, -1, 0, 0);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         long long t[32]; hipMemcpyFromSymbol(t, HIP_SYMBOL(g_smp_t), sizeof(t));
