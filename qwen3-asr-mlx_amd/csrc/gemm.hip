@@ -16,7 +16,6 @@
 // Bound: MFMA (dense bf16 peak 2.5 PFLOP/s); algorithmic flops = 2*M*N*K.
 #include "common.h"
 #include <stdlib.h>
-#include <stdio.h>
 
 #define BM 128
 #define BN 128
@@ -38,7 +37,6 @@ struct GemmParams {
     // fp8 (OCP e4m3) operands on v_mfma_f32_16x16x32_fp8_fp8 (q3asr_gemm_fp8): A and W are bytes, C = (A8 . W8^T) * a_scale[m] * w_scale[n]
     const float* a_scale; const float* w_scale;
     unsigned long long* stamp;   // diagnostic (q3asr_gemm_set_stamp): workgroup 0 records wall_clock64() at its phase boundaries
-    int stagger;                 // gemm2w_kernel: 100 MHz ticks the second workgroup of every CU waits before its first tile
 };
 
 // 128-byte rows: two rows make one 256-byte bank row, so the XOR uses row >> 1 and the row parity supplies the 4th bit:
@@ -806,232 +804,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the ring's tail DMAs (clamped re-loads) must land before exit
 }
 
-// ---------------------------------------------------------------------------
-// 256x128x64 half-tiles, TWO workgroups per CU (round 3).
-//
-// What the 8-phase kernel above leaves on the table (profiles/r02_gemm_stamps.txt): a CU holds ONE 256^2 tile, so the
-// K loop (MFMA-bound) and the epilogue (an HBM-bound burst: every CU writes its tile at the same moment) never overlap,
-// and a grid of 784 / 588 / 196 tiles leaves a quarter of the last round's slots empty.  Here a workgroup is 4 waves
-// (one per SIMD, 256 VGPRs each) on a 256 x 128 tile with an 80 KiB ring, so two workgroups share a CU: while one is in
-// its epilogue, in its pipeline fill or waiting at a barrier, the other one's MFMAs have the matrix pipes to themselves,
-// and the scheduling unit is half as large (1,568 / 1,176 / 392 tiles dealt dynamically over 512 slots).
-//
-// A wave owns 128 x 64 of the output (the 8-phase kernel's wave tile: 8 x 4 MFMA tiles, 0.375 LDS fragment reads per
-// MFMA).  A K tile is three 16 KiB half-tiles -- B (128 weight rows), A0, A1 (128 activation rows each) -- written by
-// global_load_lds_dwordx4 into a ring of 5 slots (half-tile s lives in slot s % 5, same swizzled image as above:
-// lane-linear rows of 128 bytes, k slot ^ (row >> 1) & 7 applied to the source address and to the fragment read).
-// Per K tile: read the B fragments and the first half of the A fragments (16 x ds_read_b128); issue the reads of the
-// second half; 32 MFMAs; barrier (every wave holds its fragments: the tile's three slots are free); issue the DMA of
-// half-tiles 3t+5 .. 3t+7 into them; 32 MFMAs; s_waitcnt vmcnt(8) (tile t+1 has landed, two half-tiles stay in
-// flight); barrier.  One k-ascending MFMA chain per output element, the order of the other kernels: bit-identical.
-// ---------------------------------------------------------------------------
-#define G2W_SLOT 16384
-#define G2W_LDS (5 * G2W_SLOT)
-
-// DIAG (tools/gemm_stamps.py, never the product): wave 0 of the middle workgroup accumulates s_memtime differences per loop
-// segment -- fragment reads, first MFMA block, mid-tile barrier, DMA issue, second MFMA block, end-of-tile wait + barrier --
-// and stores the sums (shader cycles) to p.stamp[0..8] (+ prologue, K loop, epilogue totals).
-#define G2W_T(IDX)                                                                                   \
-    do {                                                                                             \
-        if constexpr (DIAG) {                                                                        \
-            unsigned long long now_;                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                       \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");             \
-            __builtin_amdgcn_sched_barrier(0);                                                       \
-            seg[IDX] += now_ - last_;                                                                \
-            last_ = now_;                                                                            \
-        }                                                                                            \
-    } while (0)
-
-template <int MODE, bool DIAG = false>      // MODE 0: bf16 operands, 2: fp8 (e4m3 x e4m3, scales in the epilogue)
-__global__ __launch_bounds__(256, 2) void gemm2w_kernel(const GemmParams p, int total_tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem2w[];         // the only LDS object: 5 ring slots; the epilogue re-uses them
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int TM = 256, TN = 128;
-    const int tiles_n = (p.N + TN - 1) / TN, tiles_m = (p.M + TM - 1) / TM;
-    const int group = GROUP_M * tiles_n;
-    const unsigned t = xcd_remap(blockIdx.x, (unsigned)total_tiles);
-    const int first_m = (t / group) * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    const int m0 = (first_m + (int)(t % group) % gm) * TM;
-    const int n0 = ((int)(t % group) / gm) * TN;
-    const int wr = wave >> 1, wc = wave & 1, g = lane >> 4, li = lane & 15;
-    const int nk = MODE == 2 ? p.K / 128 : p.K / BK;                       // K tiles: 128 bytes of k per tile row
-
-    // ---- DMA state: 4 pieces (1 KiB per wave instruction) per half-tile and wave; piece q covers rows 32 q + 8 wave + lane / 8
-    const int r8 = 8 * wave + (lane >> 3);
-    const unsigned kslot = (unsigned)(((lane & 7) ^ ((r8 >> 1) & 7)) << 4);   // byte offset of the k slot whose bytes belong at this lane's position
-    const unsigned lda2 = (unsigned)(p.lda * (MODE == 2 ? 1 : 2)), ldw2 = (unsigned)(p.ldw * (MODE == 2 ? 1 : 2));
-    unsigned offB[4], offA[2][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        offB[q] = (unsigned)min(n0 + 32 * q + r8, p.N - 1) * ldw2 + kslot;
-        offA[0][q] = (unsigned)min(m0 + 32 * q + r8, p.M - 1) * lda2 + kslot;
-        offA[1][q] = (unsigned)min(m0 + 128 + 32 * q + r8, p.M - 1) * lda2 + kslot;
-    }
-    const char* Ab = reinterpret_cast<const char*>(p.A);
-    const char* Wb = reinterpret_cast<const char*>(p.W);
-    auto issue = [&](int kind, int kt, int slot) {                         // kind 0: B, 1: A0, 2: A1 (uniform)
-        char* dst = smem2w + slot * G2W_SLOT + wave * 1024;
-        const unsigned kb = (unsigned)kt * 128u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const char* src = kind == 0 ? Wb + (offB[q] + kb) : (kind == 1 ? Ab + (offA[0][q] + kb) : Ab + (offA[1][q] + kb));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + 4096 * q), 16, 0, 0);
-        }
-    };
-    // fragment read offsets inside a half-tile (kk = 0; kk = 1 is ^ 64): A rows 16 i + li, B rows 64 wc + 16 j + li
-    const unsigned rdA = (unsigned)(li * 128 + ((g ^ (li >> 1)) << 4));
-    const unsigned rdB = (unsigned)((wc * 64 + li) * 128 + ((g ^ (li >> 1)) << 4));
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Two workgroups that start together on a CU and do equal work stay in lockstep: both read fragments, both issue MFMAs,
-    // both run their epilogue at the same moments, and nothing overlaps.  The workgroups that take the CUs' second slots at
-    // launch (blocks 256..511 under the observed breadth-first placement; speed only, never correctness) start half a tile
-    // late, and since every later workgroup starts when its predecessor ends, the offset persists for the whole grid.
-    if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        const unsigned long long t0_ = wall_clock64();
-        while (wall_clock64() - t0_ < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(64);
-    }
-    unsigned long long seg[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
-    unsigned long long census_t0 = 0;
-    if constexpr (DIAG) census_t0 = wall_clock64();
-    if constexpr (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory"); }
-    // ---- prologue: half-tiles 0..4 in flight (K tile 0 and B, A0 of K tile 1); K tile 0 landed before the first read
-    issue(0, 0, 0); issue(1, 0, 1); issue(2, 0, 2); issue(0, 1, 3); issue(1, 1, 4);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    G8_BAR();
-    G2W_T(6);
-    int sB = 0, sA = 1 + wr;                                               // slots of this K tile's B and of this wave row's A half
-    for (int kt = 0; kt < nk; ++kt) {
-        bf16x8 bfr[4][2], afr[8][2];
-        const char* pb = smem2w + sB * G2W_SLOT;
-        const char* pa = smem2w + sA * G2W_SLOT;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bfr[j][0] = *reinterpret_cast<const bf16x8*>(pb + (rdB + j * 2048));
-            bfr[j][1] = *reinterpret_cast<const bf16x8*>(pb + ((rdB + j * 2048) ^ 64u));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            afr[i][0] = *reinterpret_cast<const bf16x8*>(pa + (rdA + i * 2048));
-            afr[i][1] = *reinterpret_cast<const bf16x8*>(pa + ((rdA + i * 2048) ^ 64u));
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                // lgkmcnt(0) as a builtin: the compiler's own wait insertion sees it (the
-        __builtin_amdgcn_sched_barrier(0);                                 // counter holds 15: 24 reads in flight would force a full drain before the first MFMA)
-        G2W_T(0);
-#pragma unroll
-        for (int i = 4; i < 8; ++i) {                                      // second half of the A fragments: in flight under the first 32 MFMAs
-            afr[i][0] = *reinterpret_cast<const bf16x8*>(pa + (rdA + i * 2048));
-            afr[i][1] = *reinterpret_cast<const bf16x8*>(pa + ((rdA + i * 2048) ^ 64u));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (MODE == 2) {
-                        typedef long l64x2 __attribute__((ext_vector_type(2)));
-                        const l64x2 wb = __builtin_bit_cast(l64x2, bfr[j][kk]), ab = __builtin_bit_cast(l64x2, afr[i][kk]);
-                        f32x4 c = acc[j][i];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[0], ab[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[1], ab[1], c, 0, 0, 0);
-                        acc[j][i] = c;
-                    } else {
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][kk], afr[i][kk], acc[j][i], 0, 0, 0);
-                    }
-                }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        G2W_T(1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // every fragment of this K tile is in registers
-        G8_BAR();                                                          // ... in every wave: the tile's three slots are free
-        G2W_T(2);
-        // half-tiles 3 kt + 5 .. 3 kt + 7 go into the slots just freed (slot(s + 5) = slot(s))
-        if (kt + 1 < nk) issue(2, kt + 1, sB);                             // A1 of K tile kt + 1 -> this tile's B slot
-        if (kt + 2 < nk) {
-            const int s1 = sB + 1 >= 5 ? sB - 4 : sB + 1, s2 = sB + 2 >= 5 ? sB - 3 : sB + 2;
-            issue(0, kt + 2, s1);                                          // B of K tile kt + 2 -> this tile's A0 slot
-            issue(1, kt + 2, s2);                                          // A0 of K tile kt + 2 -> this tile's A1 slot
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        G2W_T(3);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 4; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (MODE == 2) {
-                        typedef long l64x2 __attribute__((ext_vector_type(2)));
-                        const l64x2 wb = __builtin_bit_cast(l64x2, bfr[j][kk]), ab = __builtin_bit_cast(l64x2, afr[i][kk]);
-                        f32x4 c = acc[j][i];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[0], ab[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[1], ab[1], c, 0, 0, 0);
-                        acc[j][i] = c;
-                    } else {
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j][kk], afr[i][kk], acc[j][i], 0, 0, 0);
-                    }
-                }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        G2W_T(4);
-        if (kt + 1 < nk) {                                                 // K tile kt + 1 must have landed, in every wave's view
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // B, A0 of K tile kt + 2 stay in flight
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            G8_BAR();
-        }
-        G2W_T(5);
-        sB = sB + 3 >= 5 ? sB - 2 : sB + 3;
-        sA = sA + 3 >= 5 ? sA - 2 : sA + 3;
-    }
-    // nothing is in flight and every wave is past its last fragment read (the mid-tile barrier of the last K tile): the
-    // ring is free, each wave stages its epilogue blocks in 4 KiB of it
-    if constexpr (MODE == 2) {
-        int lane2 = lane;
-        asm volatile("" : "+v"(lane2));
-        const int g2 = lane2 >> 4, li2 = lane2 & 15;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nb = min(n0 + wc * 64 + j * 16 + 4 * g2, p.N - 4);
-            const f32x4 sw = *reinterpret_cast<const f32x4*>(p.w_scale + nb);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float sa = p.a_scale[min(m0 + wr * 128 + i * 16 + li2, p.M - 1)];
-                acc[j][i] *= sw * sa;
-            }
-        }
-    }
-    if (p.lds_epi) gemm_epilogue_lds(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, smem2w + wave * 4096, lane);
-    else gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
-    if constexpr (DIAG) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        G2W_T(7);
-        if (p.stamp && blockIdx.x == gridDim.x / 2 && tid == 0)
-#pragma unroll
-            for (int i = 0; i < 9; ++i) p.stamp[i] = seg[i];
-        if (p.stamp && tid == 0) {                                          // census: where and when every workgroup ran
-            unsigned hw, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* c = p.stamp + 16 + 4 * (long)blockIdx.x;
-            c[0] = hw; c[1] = xcc; c[2] = census_t0; c[3] = wall_clock64();
-        }
-    }
-}
-#undef G2W_T
-
 static int g_gemm_mode = -1;                                 // Q3ASR_GEMM or q3asr_gemm_force_kernel
 static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_stamp
 
@@ -1041,8 +813,7 @@ static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_s
 extern "C" int q3asr_gemm_set_stamp(void* buf) { g_gemm_stamp = (unsigned long long*)buf; return 0; }
 
 extern "C" int q3asr_gemm_force_kernel(int mode) {
-    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 256 || mode == 8 || mode == 2,
-               "gemm_force_kernel: mode %d (0 auto, 128, 256, 8 = 8-phase, 2 = 256x128 half-tiles at two workgroups per CU)", mode);
+    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 256 || mode == 8, "gemm_force_kernel: mode %d (0 auto, 128, 256, 8 = 8-phase)", mode);
     g_gemm_mode = mode;
     return 0;
 }
@@ -1064,35 +835,13 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
     const bool can8c = conv && p.K >= 256 && (long)p.N * p.ldw < (1L << 31) &&
                        (256L / (p.Hout * p.Wout) + 3) * p.Hin * p.Win * p.Cin * 2 < (1L << 31);
     const bool want8c = can8c && tiles256 >= 192;
-    // 256x128 half-tiles, two workgroups per CU (gemm2w_kernel): plain GEMMs with K % 64 == 0, K >= 128
-    const bool can2 = fast && p.K >= 128;
-    static const int auto2 = [] { const char* e = getenv("Q3ASR_GEMM_2W"); return e ? atoi(e) : 0; }();
-    if ((mode == 2 && can2) || (mode == 0 && auto2 && can2 && want8)) {
-        GemmParams p2 = p;
-        const long esz = p.out_kind == 1 ? 4 : 2;
-        p2.lds_epi = p.N % 8 == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0 && (p.ldo * esz) % 16 == 0 &&
-                     (p.res_kind == 0 || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) && (!p.bias || ((uintptr_t)p.bias & 15) == 0);
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm2w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2W_LDS); attr2 = true; }
-        const unsigned tiles2w = (unsigned)((p.M + 255) / 256) * (unsigned)((p.N + 127) / 128);
-        static const int stag = [] { const char* e = getenv("Q3ASR_GEMM_STAGGER"); return e ? atoi(e) : 70; }();   // ticks per K tile
-        p2.stagger = tiles2w > 256u ? stag * (p.K / BK) : 0;
-        static const bool dbg = getenv("Q3ASR_GEMM_DEBUG") != nullptr;
-        if (dbg) {
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm2w_kernel<0>, 256, G2W_LDS);
-            fprintf(stderr, "[q3asr] gemm2w: occupancy API says %d workgroups per CU (LDS %d B), %u tiles\n", nb, G2W_LDS, tiles2w);
-        }
-        if (g_gemm_stamp) {                                                  // diagnostic build of the same kernel (tools/gemm_stamps.py)
-            p2.stamp = g_gemm_stamp;
-            (void)hipFuncSetAttribute((const void*)gemm2w_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2W_LDS);
-            hipLaunchKernelGGL((gemm2w_kernel<0, true>), dim3(tiles2w), dim3(256), G2W_LDS, s, p2, (int)tiles2w);
-            return;
-        }
-        hipLaunchKernelGGL(gemm2w_kernel<0>, dim3(tiles2w), dim3(256), G2W_LDS, s, p2, (int)tiles2w);
-        return;
-    }
     if ((mode == 8 && (can8 || can8c)) || (mode == 0 && (want8 || want8c))) {      // deep-pipelined 8-phase kernel
+        // Tried (round 3, commit 'Experiment: 256x128 half-tile GEMM ...', profiles/r03_gemm2w_experiment.txt): 256 x 128 tiles, 4 waves and
+        // an 80 KiB ring so that TWO workgroups share a CU (one's epilogue and pipeline fill under the other's K loop, half-size
+        // scheduling units): bit-identical and race-screened, but no faster -- fc1 144.9 vs 143.7 us, encoder qkv 85.9 vs 82.3,
+        // prefill down 322 vs 288: the half-tile moves 1.5x the operand bytes per flop, so a wave's serial LDS-read + DMA-issue
+        // time per K tile (620 + 700 cycles, + 340 of waits) exceeds its 1,024 MFMA cycles and the pipes idle 30 % of the loop,
+        // which eats what the overlap (two workgroups resident 55-88 % of the time) and the finer tail give back.
         // Tried (round 2, tools/ab_gemm_split.py): giving the rows of a mostly empty last round (784 tiles = 3.06 rounds) to the
         // 128^2 kernel as a second launch -- fc1 142.5 -> 139.4 us, encoder qkv 88.7 -> 95.3 us, prefill qkv 200.6 -> 198.7 us: a
         // K = 1024 tile of the 128^2 kernel plus the extra launch costs what the idle CUs of the last round cost.  Not kept.
@@ -1225,15 +974,6 @@ extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale,
     Q3_REQUIRE(((uintptr_t)out & 15) == 0 && ((uintptr_t)w_scale & 15) == 0 && (res_kind == 0 || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0)),
                "gemm_fp8: out / w_scale / res must be 16-byte aligned");
     p.lds_epi = 1;
-    if (g_gemm_mode < 0) { const char* e = getenv("Q3ASR_GEMM"); g_gemm_mode = e ? atoi(e) : 0; }
-    static const int auto2f = [] { const char* e = getenv("Q3ASR_GEMM_2W"); return e ? atoi(e) : 0; }();
-    if (g_gemm_mode == 2 || (g_gemm_mode == 0 && auto2f)) {               // 256x128 half-tiles, two workgroups per CU
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void*)gemm2w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G2W_LDS); attr2 = true; }
-        const unsigned tiles2w = (unsigned)((M + 255) / 256) * (unsigned)((N + 127) / 128);
-        hipLaunchKernelGGL(gemm2w_kernel<2>, dim3(tiles2w), dim3(256), G2W_LDS, (hipStream_t)stream, p, (int)tiles2w);
-        return q3_check_launch("gemm_fp8");
-    }
     const unsigned tiles256 = (unsigned)((M + G2_T - 1) / G2_T) * (unsigned)((N + G2_T - 1) / G2_T);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS); attr = true; }
