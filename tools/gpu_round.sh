@@ -48,7 +48,9 @@ for step in "$@"; do
     stats)        prof stats decode,encoder,prefill,step --kernel-trace --stats
                   find $O/${TAG}_stats -name '*kernel_stats.csv' -exec head -30 {} \; ;;
     trace_graph)  rm -rf $O/${TAG}_trace_graph; run 420 $O/${TAG}_trace_graph.log rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_graph -- python3 $R/tools/pmc_probe.py graph4
-                  python3 $R/tools/agg_trace.py $(find $O/${TAG}_trace_graph -name '*kernel_trace.csv') 24 > $O/${TAG}_trace_graph.txt; cat $O/${TAG}_trace_graph.txt; find $O/${TAG}_trace_graph -name '*.csv' -size +20M -delete ;;
+                  python3 $R/tools/agg_trace.py $(find $O/${TAG}_trace_graph -name '*kernel_trace.csv') 24 > $O/${TAG}_trace_graph.txt; cat $O/${TAG}_trace_graph.txt
+                  python3 $R/tools/in_situ.py $(find $O/${TAG}_trace_graph -name '*kernel_trace.csv') $O/pmc_probe_meta.json $O/${TAG}_decode_in_situ.json
+                  find $O/${TAG}_trace_graph -name '*.csv' -size +20M -delete ;;
     trace_graph1) rm -rf $O/${TAG}_trace_graph1; run 420 $O/${TAG}_trace_graph1.log rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_trace_graph1 -- python3 $R/tools/pmc_probe.py graph4 --batch 1
                   python3 $R/tools/agg_trace.py $(find $O/${TAG}_trace_graph1 -name '*kernel_trace.csv') 24 > $O/${TAG}_trace_graph1.txt; cat $O/${TAG}_trace_graph1.txt; find $O/${TAG}_trace_graph1 -name '*.csv' -size +20M -delete ;;
     ab_chains)    run 400 $O/${TAG}_ab_chains.log python3 $R/tools/ab_chains.py ${AB_CHAINS_ARGS:-32 30 128 6 1,2,4} ; grep chains $O/${TAG}_ab_chains.log ;;

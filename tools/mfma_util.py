@@ -33,7 +33,8 @@ for key in busy:
         row["effective_clock_GHz"] = round(g / 8 / ns, 3)
     rows.append(row)
 rows.sort(key=lambda r: -r["mfma_busy_cycles"] * r["dispatches"])
-out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/bench_gemm.py 2",
+out = {"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/pmc_probe.py encoder,prefill "
+                  "(tools/gpu_round.sh <tag> mfma): one mel + encoder pass and one prefill of 32 x 30 s clips at the 1.7B shapes, in situ",
        "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)", "kernels": rows[:20]}
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)
