@@ -62,8 +62,8 @@ int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, int Cin, con
 int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
                     const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
                     void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream);
-/* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 128 = 128x128 tile, 256 = 256x256 register-staged,
- * 8 = 256x256 8-phase LDS-DMA pipeline where its preconditions hold).  All kernels give bit-identical results. */
+/* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 128 = 128x128 tile, 8 = 256x256 8-phase LDS-DMA pipeline
+ * where its preconditions hold).  Both kernels give bit-identical results. */
 int q3asr_gemm_force_kernel(int mode);
 /* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
 int q3asr_gemm_set_stamp(void* buf);
@@ -125,14 +125,6 @@ int q3asr_qk_norm_rope_kv(const void* qkv, int is_slab, int64_t ld, int n_slabs,
                           int nh, int nkv, int head_dim, int Lmax, void* stream);
 
 /* ---- decode step (generate.py:289-313 -> decoder.py:219-253 at T=1), M = batch <= 64 --------- */
-int q3asr_embed_rmsnorm(const int32_t* tok, const void* E, int V, void* h_out, const void* w, void* x_out, int M, int N,
-                        float eps, void* stream);
-/* C = X[M,K] . W[N,K]^T, weight-streaming; n_splits>1 writes fp32 slabs [n_splits][M][N]. */
-int q3asr_skinny_gemm(const void* X, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, int n_splits,
-                      float* slab, void* out, int64_t ldo, void* stream);
-int q3asr_slab_residual_rmsnorm(const float* slab, int n_slabs, int64_t slab_stride, const void* h_in, void* h_out,
-                                const void* w, void* x_out, int M, int N, float eps, void* stream);
-int q3asr_slab_swiglu(const float* slab, int n_slabs, int64_t slab_stride, void* act, int M, int I, void* stream);
 /* ---- streaming layouts of the graph-captured decode step (csrc/decode.hip) ---------------------
  * W16 [N/16][K/32][64][8]: lane (g=lane>>4, li=lane&15) holds W[16rt+li][32ks+8g+j];
  * X16 [K/32][MT][64][8]:   lane holds X[16mt+li][32ks+8g+j], MT = 1/2/4 for M <= 16/32/64.
@@ -182,14 +174,12 @@ int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, void* h_out, 
  * through `workspace` (q3asr_attn_decode_fused_workspace(B, nkv, Lmax) bytes, zero-filled once by the caller,
  * left zeroed/ready by every launch; launches sharing a workspace must be ordered on one stream). */
 int64_t q3asr_attn_decode_fused_workspace(int B, int nkv, int Lmax);
-/* Test / A-B hook: non-zero selects the lane-group dot-product (VALU) formulation instead of the MFMA one. */
-int q3asr_attn_decode_force_valu(int on);
+/* Test hook: pin the number of 1,024-token cache chunks one workgroup sweeps (0 = automatic).  Results do not depend on it. */
+int q3asr_attn_decode_set_chunks_per_wg(int n);
 int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_slabs, int64_t slab_stride, const void* qn_w,
                             const void* kn_w, const float* inv_freq, float eps, void* k_cache, void* v_cache,
                             const int32_t* pos, void* out16, int B, int nh, int nkv, int head_dim, int Lmax,
                             float scale, void* workspace, void* stream);
-int q3asr_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
-                      int B, int nh, int nkv, int head_dim, int Lmax, float scale, void* stream);
 
 /* ---- generate.py:88-215 `sample` + loop bookkeeping :286-313, one launch per step ------------ */
 /* finished[b]: 0 running, 1 ended (EOS or budget), Q3ASR_ROW_FAILED: the row's logits had no valid maximum / draw (non-finite

@@ -34,8 +34,6 @@ _SIGS = {
     "q3asr_attn_fwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "q3asr_embed_merge": [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "q3asr_qk_norm_rope_kv": [_vp, _i, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "q3asr_embed_rmsnorm": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp],
-    "q3asr_skinny_gemm": [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_skinny3_gemm": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_skinny4_gemm": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
     "q3asr_skinny4_gemm_norm": [_vp, _i, _i64, _vp, _vp, _vp, _f, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
@@ -43,11 +41,8 @@ _SIGS = {
     "q3asr_slab_resnorm_x16": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_embed_norm_x16": [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_attn_decode_fused_workspace": [_i, _i, _i],
-    "q3asr_attn_decode_force_valu": [_i],
+    "q3asr_attn_decode_set_chunks_per_wg": [_i],
     "q3asr_attn_decode_fused": [_vp, _i64, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
-    "q3asr_slab_residual_rmsnorm": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
-    "q3asr_slab_swiglu": [_vp, _i, _i64, _vp, _i, _i, _vp],
-    "q3asr_attn_decode": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp],
     "q3asr_sample_step": [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _u64, _i, _i, _i, _vp],
     "q3asr_graph_begin": [_vp],
     "q3asr_graph_end": [_vp, C.POINTER(_vp)],

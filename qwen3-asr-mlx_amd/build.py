@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libq3asr_hip.so"
-SOURCES = ["core.hip", "mel.hip", "gemm.hip", "norm.hip", "elementwise.hip", "attn.hip", "skinny.hip", "decode.hip", "sampling.hip", "parity.hip"]
+SOURCES = ["core.hip", "mel.hip", "gemm.hip", "norm.hip", "elementwise.hip", "attn.hip", "decode.hip", "sampling.hip", "parity.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I", str(HERE.parent / "include")]
 if os.environ.get("Q3ASR_PACKED_F32", "0") != "1":

@@ -4,7 +4,7 @@
 //        (the block-diagonal mask of encoder.py:210-229 is never materialised);
 //      - decoder prefill (decoder.py:158-163): HD=128, causal, GQA, one segment per sequence,
 //        K/V read from the KV cache the RoPE kernel just filled.
-//  * attn_decode: one new token per sequence against its cache (HBM-bound KV streaming).
+// (The decode step's attention, one new token per sequence against its cache, is attn_decode_fused_kernel in decode.hip.)
 //
 // attn_fwd maths per 64-key tile, per wave (16 query rows), MFMA 16x16x32 bf16:
 //   S^T = K . Q^T      A operand = K rows (ds_read_b128 from the swizzled LDS tile), B = Q (registers)
@@ -198,109 +198,4 @@ extern "C" int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, co
     else if (head_dim == 64 && causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, blk, 0, s, p);
     else { q3asr_set_error("attn_fwd: head_dim=%d unsupported (64 or 128)", head_dim); return Q3_EBADARG; }
     return q3_check_launch("attn_fwd");
-}
-
-// ---------------------------------------------------------------------------
-// Decode attention: one query token per sequence, 2 query heads per kv head (GQA 16/8),
-// keys 0..pos[b] of the cache.  One 512-thread workgroup per (kv head, sequence); a 16-lane
-// group owns one cached token per step (lane i: dims 8i..8i+7, one 16-byte load of K and of V),
-// so a wave-instruction reads 4 whole 256-byte rows.  Each group keeps an online-softmax
-// partial; the 32 partials are merged through LDS.  Bytes: 2 * 256 B per cached token per
-// kv head -- 114,688 B per token over 28 layers.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void attn_decode_kernel(const bf16* __restrict__ q /*[B][nh*128]*/,
-                                                          const bf16* __restrict__ k_cache, const bf16* __restrict__ v_cache,
-                                                          const int* __restrict__ pos, bf16* __restrict__ out, int nh,
-                                                          int nkv, int Lmax, float scale) {
-    __shared__ float s_m[32][2], s_l[32][2];
-    __shared__ __attribute__((aligned(16))) float s_acc[32][2][128];
-    const int kvh = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, i = lane & 15;
-    const int L = pos[b] + 1;
-    const bf16* Kb = k_cache + ((long)b * nkv + kvh) * Lmax * 128;
-    const bf16* Vb = v_cache + ((long)b * nkv + kvh) * Lmax * 128;
-    float q0[8], q1[8];
-    {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(q + (long)b * nh * 128 + (2 * kvh) * 128 + 8 * i);
-        const bf16x8 c = *reinterpret_cast<const bf16x8*>(q + (long)b * nh * 128 + (2 * kvh + 1) * 128 + 8 * i);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { q0[e] = bf2f(a[e]); q1[e] = bf2f(c[e]); }
-    }
-    float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
-    float a0[8], a1[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-    const int slot = wave * 4 + g;                       // 32 token slots per sweep
-    for (int t0 = 0; t0 < L; t0 += 64) {
-        // two tokens per group per iteration keeps 4 x 16 B per lane in flight
-        bf16x8 kk[2], vv[2];
-        bool ok[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int t = t0 + 32 * u + slot;
-            ok[u] = t < L;
-            const int tc = ok[u] ? t : 0;
-            kk[u] = *reinterpret_cast<const bf16x8*>(Kb + (long)tc * 128 + 8 * i);
-            vv[u] = *reinterpret_cast<const bf16x8*>(Vb + (long)tc * 128 + 8 * i);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float kf = bf2f(kk[u][e]);
-                d0 = fmaf(q0[e], kf, d0);
-                d1 = fmaf(q1[e], kf, d1);
-            }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                d0 += __shfl_xor(d0, o, 64);
-                d1 += __shfl_xor(d1, o, 64);
-            }
-            if (ok[u]) {
-                const float s0 = d0 * scale, s1 = d1 * scale;
-                const float n0 = fmaxf(m0, s0), n1 = fmaxf(m1, s1);
-                const float al0 = __expf(m0 - n0), al1 = __expf(m1 - n1);
-                const float p0 = __expf(s0 - n0), p1 = __expf(s1 - n1);
-                l0 = l0 * al0 + p0;
-                l1 = l1 * al1 + p1;
-                m0 = n0;
-                m1 = n1;
-                const float pb0 = round_bf(p0), pb1 = round_bf(p1);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float vf = bf2f(vv[u][e]);
-                    a0[e] = fmaf(pb0, vf, a0[e] * al0);
-                    a1[e] = fmaf(pb1, vf, a1[e] * al1);
-                }
-            }
-        }
-    }
-    if (i == 0) { s_m[slot][0] = m0; s_m[slot][1] = m1; s_l[slot][0] = l0; s_l[slot][1] = l1; }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { s_acc[slot][0][8 * i + e] = a0[e]; s_acc[slot][1][8 * i + e] = a1[e]; }
-    __syncthreads();
-    if (tid < 256) {
-        const int h = tid >> 7, d = tid & 127;
-        float M = -INFINITY;
-        for (int s = 0; s < 32; ++s) M = fmaxf(M, s_m[s][h]);
-        float num = 0.f, den = 0.f;
-        for (int s = 0; s < 32; ++s) {
-            const float w = __expf(s_m[s][h] - M);       // empty partial: exp(-inf) = 0
-            num = fmaf(s_acc[s][h][d], w, num);
-            den = fmaf(s_l[s][h], w, den);
-        }
-        out[(long)b * nh * 128 + (2 * kvh + h) * 128 + d] = f2bf(num / den);
-    }
-}
-
-extern "C" int q3asr_attn_decode(const void* q, const void* k_cache, const void* v_cache, const int32_t* pos, void* out,
-                                 int B, int nh, int nkv, int head_dim, int Lmax, float scale, void* stream) {
-    Q3_REQUIRE(q && k_cache && v_cache && pos && out, "attn_decode: null pointer");
-    Q3_REQUIRE(head_dim == 128 && nh == 2 * nkv, "attn_decode: needs head_dim 128 and 2 query heads per kv head (got %d, %d/%d)", head_dim, nh, nkv);
-    Q3_REQUIRE(B > 0 && Lmax > 0, "attn_decode: bad sizes");
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(nkv, B), dim3(512), 0, (hipStream_t)stream, (const bf16*)q, (const bf16*)k_cache,
-                       (const bf16*)v_cache, pos, (bf16*)out, nh, nkv, Lmax, scale);
-    return q3_check_launch("attn_decode");
 }

@@ -760,8 +760,8 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, vo
 // Workgroup (kv head, sequence, group of 1024-token chunks of the cache).  Waves 0,1 normalise/rotate the two query
 // heads; in the chunk that holds the new token waves 2,3 do the same for k and pass v through, and the new
 // k/v go to the cache AND to LDS (the token attends to itself without a global round trip).  A chunk is
-// swept in 128-token batches through a register double buffer (2 x 64 KiB in flight, the first batch issued
-// before the prologue); 32 token slots keep online-softmax partials, merged through LDS.
+// swept in 32-key MFMA tiles, wave w owning tiles w, w + 8, ... (the first one issued before the prologue); the
+// waves' online-softmax partials are merged through LDS.
 // Sequences longer than one chunk: every chunk writes (max, sum, numerator[128]) per head to the workspace,
 // and the LAST workgroup to arrive (device-scope counter) merges the chunks in chunk order, so the result
 // depends only on the sequence, not on the batch, the cache capacity or the arrival order.
@@ -783,8 +783,8 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, vo
 // writes and for the transposing reads (same image as the prefill kernel, attn.hip)
 __device__ __forceinline__ int adm_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-// NT (MFMA path): the cached keys / values are read with non-temporal loads (a cache that is streamed once per step).
-template <bool MFMA, bool NT = false>
+// NT: the cached keys / values are read with non-temporal loads (a cache that is streamed once per step).
+template <bool NT>
 __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
                                                                 const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
                                                                 const float* __restrict__ inv_freq, float eps,
@@ -792,15 +792,14 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                                                                 const int* __restrict__ pos_arr, bf16* __restrict__ out16,
                                                                 int MT, int nh, int nkv, int Lmax, float scale,
                                                                 float* part, int* counters, int nc, int G) {
-    constexpr int NP = MFMA ? 8 : 32;                                 // partials merged per chunk: one per wave / per token slot
-    __shared__ float s_q[2][128];
+    constexpr int NP = 8;                                             // partials merged per chunk: one per wave
     __shared__ __attribute__((aligned(16))) bf16 s_qb[2][128];
     __shared__ __attribute__((aligned(16))) bf16 s_k[128], s_v[128];
     __shared__ float s_m[NP][2], s_l[NP][2];
     __shared__ __attribute__((aligned(16))) float s_acc[NP][2][128];
     __shared__ int s_ticket;
     __shared__ float s_part[ADF_LOCAL_MAX][ADF_PART];                  // per-chunk partials of a workgroup that owns the whole sequence
-    extern __shared__ __attribute__((aligned(16))) char adm_tiles[];   // MFMA: one 32-key V tile (8 KiB) per wave
+    extern __shared__ __attribute__((aligned(16))) char adm_tiles[];   // one 32-key V tile (8 KiB) per wave
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int pos = pos_arr[b];
     const int L = pos + 1, n_active = (L + ADF_CHUNK - 1) / ADF_CHUNK;
@@ -813,16 +812,8 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     const int g = lane >> 4, i = lane & 15;
     bf16* Kb = k_cache + ((long)b * nkv + kvh) * Lmax * 128;
     bf16* Vb = v_cache + ((long)b * nkv + kvh) * Lmax * 128;
-    const int slot = wave * 4 + g;                                    // 32 token slots per 32-token sweep
     const int t0 = c_begin * ADF_CHUNK;
-    bf16x8 kA[4], vA[4], kB[4], vB[4];
     const int t_last = pos > 0 ? pos - 1 : 0;                         // tokens >= pos are never read from the cache
-#define Q3_LOAD_BATCH(KK, VV, T0)                                                                   \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
-        const int t_ = min((T0) + 32 * u + slot, t_last);                                           \
-        KK[u] = *reinterpret_cast<const bf16x8*>(Kb + (long)t_ * 128 + 8 * i);                      \
-        VV[u] = *reinterpret_cast<const bf16x8*>(Vb + (long)t_ * 128 + 8 * i);                      \
-    }
     // The prologue's own loads go first: a wave's loads return in order, so the slab values must not queue behind the
     // first 64 KiB of keys and values.
     const bool pro = wave < 2 || (wave < 4 && owner);
@@ -840,8 +831,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             p2[u] = in ? src[u * slab_stride + lane + 64] : 0.f;
         }
     }
-    if constexpr (!MFMA) { Q3_LOAD_BATCH(kA, vA, t0) }
-    // MFMA path: one register set for a 32-key tile (K as A fragments, V rows on their way to LDS); the next tile's loads
+    // One register set for a 32-key tile (K as A fragments, V rows on their way to LDS); the next tile's loads
     // are issued as soon as this tile's K fed the MFMAs and its V sits in LDS.  The first tile is issued here, ahead of
     // the prologue's arithmetic.
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -858,9 +848,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
         const int c_ = lane + 64 * it;                                                                      \
         VR[it] = ADM_LD(reinterpret_cast<const u32x4*>(Vb + (long)min((TB) + (c_ >> 4), t_last) * 128 + 8 * (c_ & 15))); \
         }
-    if constexpr (MFMA) {
-        if (t0 + 32 * wave < min(L, t0 + ADF_CHUNK)) { ADM_LOAD(kR, vR, t0 + 32 * wave) }
-    }
+    if (t0 + 32 * wave < min(L, t0 + ADF_CHUNK)) { ADM_LOAD(kR, vR, t0 + 32 * wave) }
     if (pro) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -888,7 +876,6 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             sincosf((float)pos * freq, &sn, &cs);
             const float o1 = round_bf(y1 * cs - y2 * sn), o2 = round_bf(y1 * sn + y2 * cs);
             if (wave < 2) {
-                s_q[wave][lane] = o1; s_q[wave][lane + 64] = o2;
                 s_qb[wave][lane] = f2bf(o1); s_qb[wave][lane + 64] = f2bf(o2);
             }
             else {
@@ -900,100 +887,8 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     // The first batch of cached keys/values does not depend on the prologue: it was issued above and is
     // in flight across this barrier.
     __syncthreads();
-    if constexpr (!MFMA) {
-    float q0[8], q1[8];
-    #pragma unroll
-        for (int e = 0; e < 8; ++e) { q0[e] = s_q[0][8 * i + e]; q1[e] = s_q[1][8 * i + e]; }
-        float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
-        float a0[8], a1[8];
-    #pragma unroll
-        for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-    #define Q3_COMPUTE(KK, VV, T0)                                                                      \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                 \
-            const int t = (T0) + 32 * u + slot;                                                         \
-            bf16x8 kf8 = KK[u], vf8 = VV[u];                                                            \
-            if (t == pos) { /* the new token: from LDS, not from HBM */                                 \
-                kf8 = *reinterpret_cast<const bf16x8*>(s_k + 8 * i);                                    \
-                vf8 = *reinterpret_cast<const bf16x8*>(s_v + 8 * i);                                    \
-            }                                                                                           \
-            float d0 = 0.f, d1 = 0.f;                                                                   \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                             \
-                const float kf = bf2f(kf8[e]);                                                          \
-                d0 = fmaf(q0[e], kf, d0);                                                               \
-                d1 = fmaf(q1[e], kf, d1);                                                               \
-            }                                                                                           \
-            _Pragma("unroll") for (int o = 1; o < 16; o <<= 1) {                                        \
-                d0 += __shfl_xor(d0, o, 64);                                                            \
-                d1 += __shfl_xor(d1, o, 64);                                                            \
-            }                                                                                           \
-            if (t <= pos) {                                                                             \
-                const float s0 = d0 * scale, s1 = d1 * scale;                                           \
-                const float n0 = fmaxf(m0, s0), n1 = fmaxf(m1, s1);                                     \
-                const float al0 = __expf(m0 - n0), al1 = __expf(m1 - n1);                               \
-                const float p0 = __expf(s0 - n0), p1 = __expf(s1 - n1);                                 \
-                l0 = l0 * al0 + p0;                                                                     \
-                l1 = l1 * al1 + p1;                                                                     \
-                m0 = n0;                                                                                \
-                m1 = n1;                                                                                \
-                const float pb0 = round_bf(p0), pb1 = round_bf(p1);                                     \
-                _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                         \
-                    const float vf = bf2f(vf8[e]);                                                      \
-                    a0[e] = fmaf(pb0, vf, a0[e] * al0);                                                 \
-                    a1[e] = fmaf(pb1, vf, a1[e] * al1);                                                 \
-                }                                                                                       \
-            }                                                                                           \
-        }
-    const int t_end = min(L, c_end * ADF_CHUNK);
-        const int h = (tid >> 7) & 1, d = tid & 127;
-        float* my = part + (((long)b * nkv + kvh) * nc) * ADF_PART;
-    for (int tt = t0; tt < t_end; tt += 256) {                         // register double buffer: 2 x 64 KiB per workgroup in flight
-            if (tt + 128 < t_end) { Q3_LOAD_BATCH(kB, vB, tt + 128) }
-            Q3_COMPUTE(kA, vA, tt)
-            if (tt + 256 < t_end) { Q3_LOAD_BATCH(kA, vA, tt + 256) }
-            if (tt + 128 < t_end) { Q3_COMPUTE(kB, vB, tt + 128) }
-            if (((tt + 256) % ADF_CHUNK) != 0 && tt + 256 < t_end) continue;
-            // ---- end of a chunk: merge the 32 slots (the next chunk's first batch is already in flight)
-            if (i == 0) { s_m[slot][0] = m0; s_m[slot][1] = m1; s_l[slot][0] = l0; s_l[slot][1] = l1; }
-    #pragma unroll
-            for (int e = 0; e < 8; ++e) { s_acc[slot][0][8 * i + e] = a0[e]; s_acc[slot][1][8 * i + e] = a1[e]; }
-            __syncthreads();
-            if (tid < 256) {
-                float Mx = -INFINITY, num = 0.f, den = 0.f;
-                for (int s = 0; s < 32; ++s) Mx = fmaxf(Mx, s_m[s][h]);
-                for (int s = 0; s < 32; ++s) {
-                    const float w = __expf(s_m[s][h] - Mx);
-                    num = fmaf(s_acc[s][h][d], w, num);
-                    den = fmaf(s_l[s][h], w, den);
-                }
-                if (n_active == 1) {                                      // the whole sequence is this chunk
-                    out16[x16_index(b, (2 * kvh + h) * 128 + d, MT)] = f2bf(num / den);
-                } else if (local) {
-                    float* dst = s_part[tt / ADF_CHUNK] + h * 130;
-                    dst[d] = num;
-                    if (d == 0) { dst[128] = Mx; dst[129] = den; }
-                } else {
-                    // Partials travel as device-scope (write-through) atomic stores and loads, so no cache-wide
-                    // write-back or invalidate is needed.
-                    float* dst = my + (long)(tt / ADF_CHUNK) * ADF_PART + h * 130;
-                    __hip_atomic_store(dst + d, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (d == 0) {
-                        __hip_atomic_store(dst + 128, Mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(dst + 129, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-            if (tt + 256 < t_end) {                                       // another chunk follows: fresh slots
-                __syncthreads();
-                m0 = m1 = -INFINITY;
-                l0 = l1 = 0.f;
-    #pragma unroll
-                for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-            }
-        }
-#undef Q3_COMPUTE
-    }
-    if constexpr (MFMA) {
-        // ---- MFMA path: S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16, the two heads of this kv head being two
+    {
+        // ---- S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16, the two heads of this kv head being two
         // of the 16 query columns (prefill kernel's formulation, attn.hip).  Wave w owns the 32-key tiles w, w+8, ... of a
         // chunk: K goes global -> A fragment (lane (li, g): key li, dims 32 ks + 8 g), V through a wave-private LDS tile
         // and ds_read_b64_tr_b16; the next tile's K/V loads are issued between this tile's QK and its softmax / PV.
@@ -1118,7 +1013,6 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
 #undef ADM_LOAD
 #undef ADM_LD
     }
-#undef Q3_LOAD_BATCH
     if (n_active == 1) return;                                        // uniform
     const int h = (tid >> 7) & 1, d = tid & 127;
     if (local) {                                                      // same merge, same order, operands from LDS
@@ -1164,11 +1058,16 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
         __hip_atomic_store(counters + b * nkv + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
+static int g_attn_chunks_per_wg = 0;
+// Test hook: 0 = automatic; any other value pins the number of 1,024-token cache chunks a workgroup sweeps (the result does not
+// depend on it: per-chunk partials merged in chunk order -- tests/test_kernels_gpu.py).
+extern "C" int q3asr_attn_decode_set_chunks_per_wg(int n) { g_attn_chunks_per_wg = n > 0 ? n : 0; return 0; }
+
 // Chunks per workgroup for a launch: minimises rounds x (fixed cost + chunks x chunk time) (+ the cross-workgroup
 // merge when a sequence spans several workgroups), one 512-thread workgroup per CU, at the cache's capacity.
-// Any value gives the same bits (per-chunk partials, merged in chunk order); Q3ASR_ATTN_CHUNKS_PER_WG overrides.
+// Any value gives the same bits (per-chunk partials, merged in chunk order); q3asr_attn_decode_set_chunks_per_wg overrides.
 static int adf_chunks_per_wg(int pairs, int nc) {
-    static const int forced = [] { const char* e = getenv("Q3ASR_ATTN_CHUNKS_PER_WG"); return e ? atoi(e) : 0; }();
+    const int forced = g_attn_chunks_per_wg;
     if (forced > 0) return forced < nc ? forced : nc;
     const float fixed_us = 8.f, chunk_us = 24.f, merge_us = 5.f;
     int best = nc;
@@ -1181,9 +1080,6 @@ static int adf_chunks_per_wg(int pairs, int nc) {
     }
     return best;
 }
-
-static int g_attn_force_valu = 0;
-extern "C" int q3asr_attn_decode_force_valu(int on) { g_attn_force_valu = on != 0; return 0; }
 
 extern "C" int64_t q3asr_attn_decode_fused_workspace(int B, int nkv, int Lmax) {
     if (B <= 0 || nkv <= 0 || Lmax <= 0) return 0;
@@ -1203,32 +1099,23 @@ extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_
     float* part = (float*)workspace;
     int* counters = (int*)(part + (int64_t)B * nkv * nc * ADF_PART);
     const int G = adf_chunks_per_wg(B * nkv, nc);
-    // MFMA formulation by default; Q3ASR_ATTN=valu keeps the lane-group dot-product kernel (A/B, cross-check in the tests)
-    static const bool valu = [] { const char* e = getenv("Q3ASR_ATTN"); return e && e[0] == 'v'; }();
-    if (valu || g_attn_force_valu) {
-        hipLaunchKernelGGL((attn_decode_fused_kernel<false, false>), dim3(nkv, B, (nc + G - 1) / G), dim3(512), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+        (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+        attr = true;
+    }
+    // K/V larger than the caches can keep from one step to the next are streamed with non-temporal loads (batch 32, 512-token
+    // capacity: 67 MB per layer; 252 -> 250 ms per request); a small cache stays resident in L2 / Infinity Cache between steps
+    // and default-policy loads are faster there (batch 1: 162.4 vs 167.2 ms).
+    const bool nt = (int64_t)B * nkv * Lmax * 512 > (16LL << 20);
+    if (nt)
+        hipLaunchKernelGGL(attn_decode_fused_kernel<true>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
                            (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
                            nkv, Lmax, scale, part, counters, nc, G);
-    } else {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
-            (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
-            attr = true;
-        }
-        // K/V larger than the caches can keep from one step to the next are streamed with non-temporal loads (batch 32, 512-token
-        // capacity: 67 MB per layer; 252 -> 250 ms per request); a small cache stays resident in L2 / Infinity Cache between steps
-        // and default-policy loads are faster there (batch 1: 162.4 vs 167.2 ms).  Q3ASR_ATTN_NT=0/1 forces either.
-        static const int nt_forced = [] { const char* e = getenv("Q3ASR_ATTN_NT"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-        const bool nt = nt_forced >= 0 ? nt_forced == 1 : (int64_t)B * nkv * Lmax * 512 > (16LL << 20);
-        if (nt)
-            hipLaunchKernelGGL((attn_decode_fused_kernel<true, true>), dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
-                               (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
-                               nkv, Lmax, scale, part, counters, nc, G);
-        else
-            hipLaunchKernelGGL((attn_decode_fused_kernel<true, false>), dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
-                               (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
-                               nkv, Lmax, scale, part, counters, nc, G);
-    }
+    else
+        hipLaunchKernelGGL(attn_decode_fused_kernel<false>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
+                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
+                           nkv, Lmax, scale, part, counters, nc, G);
     return q3_check_launch("attn_decode_fused");
 }

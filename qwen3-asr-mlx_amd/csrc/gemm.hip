@@ -376,142 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     gemm_epilogue<4>(p, acc, m0 + wm * 64, n0 + wn * 64, n0, wn, g, li);
 }
 
-// ---------------------------------------------------------------------------
-// 256x256x64 tile for grids with >= 6 tiles per CU: 8 waves (2 x 4), each 128 x 64 = 8 x 4 MFMA tiles.
-// Same register-staged, XOR-swizzled, double-buffered structure as the 128^2 kernel, but per MFMA half
-// the LDS store bytes and 3/4 of the LDS read bytes: at 128^2 the LDS stores, the LDS reads and the MFMAs of a
-// K step were measured NOT to overlap (ablation in profiles/), so the time per flop follows the LDS bytes per flop.
-// 128 KiB of LDS, one workgroup per CU, 2 waves per SIMD.
-// ---------------------------------------------------------------------------
 #define G2_T 256
-
-template <int CONV, bool FAST = false>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem2[];          // [2 stages][A 32 KiB | W 32 KiB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (p.N + G2_T - 1) / G2_T, tiles_m = (p.M + G2_T - 1) / G2_T;
-    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
-    const int group = GROUP_M * tiles_n;
-    const int first_m = (t / group) * GROUP_M;
-    const int gm = min(tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (int)(t % group) % gm;
-    const int tn = (int)(t % group) / gm;
-    const int m0 = tm * G2_T, n0 = tn * G2_T;
-
-    const int slot = tid & 7, lrow = tid >> 3;                             // 64 rows per pass, 4 passes per operand
-    long a_base[4], w_base[4];
-    int a_ih0[4], a_iw0[4];
-    bool a_ok[4], w_ok[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int am = m0 + lrow + 64 * q;
-        a_ok[q] = am < p.M;
-        if (CONV) {
-            const int hw = p.Hout * p.Wout;
-            const int img = am / hw, rem = am - img * hw;
-            const int oh = rem / p.Wout, ow = rem - oh * p.Wout;
-            a_ih0[q] = 2 * oh - 1;
-            a_iw0[q] = 2 * ow - 1;
-            a_base[q] = (long)img * p.Hin * p.Win * p.Cin;
-        } else {
-            a_base[q] = (long)am * p.lda;
-            a_ih0[q] = a_iw0[q] = 0;
-        }
-        const int wn_ = n0 + lrow + 64 * q;
-        w_ok[q] = wn_ < p.N;
-        w_base[q] = (long)wn_ * p.ldw;
-    }
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 ra[4], rw[4];
-    unsigned fa_off[4] = {0, 0, 0, 0}, fw_off[4] = {0, 0, 0, 0};   // FAST: clamped rows, uniform base + 32-bit lane offset
-    if constexpr (FAST) {
-        fa_off[0] = (unsigned)(((long)min(m0 + lrow, p.M - 1) * p.lda + slot * 8) * 2);
-        fa_off[1] = (unsigned)(((long)min(m0 + lrow + 64, p.M - 1) * p.lda + slot * 8) * 2);
-        fa_off[2] = (unsigned)(((long)min(m0 + lrow + 128, p.M - 1) * p.lda + slot * 8) * 2);
-        fa_off[3] = (unsigned)(((long)min(m0 + lrow + 192, p.M - 1) * p.lda + slot * 8) * 2);
-        fw_off[0] = (unsigned)(((long)min(n0 + lrow, p.N - 1) * p.ldw + slot * 8) * 2);
-        fw_off[1] = (unsigned)(((long)min(n0 + lrow + 64, p.N - 1) * p.ldw + slot * 8) * 2);
-        fw_off[2] = (unsigned)(((long)min(n0 + lrow + 128, p.N - 1) * p.ldw + slot * 8) * 2);
-        fw_off[3] = (unsigned)(((long)min(n0 + lrow + 192, p.N - 1) * p.ldw + slot * 8) * 2);
-    }
-    auto load_tile = [&](int k0) {
-        const int k = k0 + slot * 8;
-        const bool kin = k < p.K;
-        int ci = 0, kh = 0, kw = 0;
-        bool cin_ok = true;
-        if (CONV) {                                          // chunk-major K (see conv3x3s2)
-            const int kt = k0 >> 6, chunk = kt / 9, tap = kt - 9 * chunk;
-            ci = chunk * 64 + slot * 8;
-            cin_ok = ci < p.Cin;
-            kh = tap / 3;
-            kw = tap - 3 * kh;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (CONV) {
-                const int ih = a_ih0[q] + kh, iw = a_iw0[q] + kw;
-                if (a_ok[q] && kin && cin_ok && ih >= 0 && ih < p.Hin && iw >= 0 && iw < p.Win)
-                    v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + ((long)(ih * p.Win + iw) * p.Cin + ci));
-            } else {
-                if (a_ok[q] && kin) v = *reinterpret_cast<const u32x4*>(p.A + a_base[q] + k);
-            }
-            ra[q] = v;
-            u32x4 w = {0u, 0u, 0u, 0u};
-            if (w_ok[q] && kin) w = *reinterpret_cast<const u32x4*>(p.W + w_base[q] + k);
-            rw[q] = w;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        char* sa = smem2 + buf * (2 * G2_T * 128);
-        char* sw = sa + G2_T * 128;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = lrow + 64 * q;
-            *reinterpret_cast<u32x4*>(sa + lds_off(r, slot)) = ra[q];
-            *reinterpret_cast<u32x4*>(sw + lds_off(r, slot)) = rw[q];
-        }
-    };
-
-    const int wm = wave >> 2, wn = wave & 3;
-    const int g = lane >> 4, li = lane & 15;
-    f32x4 acc[4][8];   // [j: n tile][i: m tile]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.K + BK - 1) / BK;
-    if constexpr (FAST) Q3_LOAD_FAST(0) else load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            if constexpr (FAST) Q3_LOAD_FAST((kt + 1) * BK) else load_tile((kt + 1) * BK);
-        }
-        const char* sa = smem2 + buf * (2 * G2_T * 128);
-        const char* sw = sa + G2_T * 128;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 wf[4], af[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                wf[j] = *reinterpret_cast<const bf16x8*>(sw + lds_off(wn * 64 + j * 16 + li, kk * 4 + g));
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 128 + i * 16 + li, kk * 4 + g));
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-    gemm_epilogue<8>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, wn, g, li);
-}
 
 // ---------------------------------------------------------------------------
 // 256x256x64 tile, 8 phases per pair of K tiles: the deep-pipelined variant for plain GEMMs (K % 128 == 0).
@@ -804,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the ring's tail DMAs (clamped re-loads) must land before exit
 }
 
-static int g_gemm_mode = -1;                                 // Q3ASR_GEMM or q3asr_gemm_force_kernel
+static int g_gemm_mode = 0;                                  // q3asr_gemm_force_kernel
 static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_stamp
 
 // Diagnostic hook: workgroup 0 of every following 8-phase launch writes up to 16 wall_clock64() stamps (100 MHz) to `buf`
@@ -813,7 +678,7 @@ static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_s
 extern "C" int q3asr_gemm_set_stamp(void* buf) { g_gemm_stamp = (unsigned long long*)buf; return 0; }
 
 extern "C" int q3asr_gemm_force_kernel(int mode) {
-    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 256 || mode == 8, "gemm_force_kernel: mode %d (0 auto, 128, 256, 8 = 8-phase)", mode);
+    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 8, "gemm_force_kernel: mode %d (0 auto, 128, 8 = 8-phase)", mode);
     g_gemm_mode = mode;
     return 0;
 }
@@ -822,15 +687,13 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
     const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
     const bool fast = !conv && p.K % BK == 0 && (long)p.M * p.lda < (1L << 31) && (long)p.N * p.ldw < (1L << 31);
     const unsigned tiles256 = (unsigned)((p.M + G2_T - 1) / G2_T) * (unsigned)((p.N + G2_T - 1) / G2_T);
-    if (g_gemm_mode < 0) { const char* e = getenv("Q3ASR_GEMM"); g_gemm_mode = e ? atoi(e) : 0; }
-    const int mode = force_mode ? force_mode : g_gemm_mode;  // 0 auto; 128 / 256 / 8 pin a kernel (A/B runs, tests)
+    const int mode = force_mode ? force_mode : g_gemm_mode;  // 0 auto; 128 / 8 pin a kernel (A/B runs, tests)
     // Kernel choice (measured on the prefill / encoder shapes, tools/bench_gemm.py): the 8-phase kernel wins wherever its
     // preconditions hold and the grid fills the chip: one 256^2 tile costs ~2.6 128^2 tiles, one workgroup per CU against
     // two (fc1 with its erf-GELU epilogue: 156 us against 181 us).
     const bool can8 = fast && p.K % 128 == 0 && p.K >= 256;
     const unsigned rounds8 = (tiles256 + 255) / 256, rounds128 = (tiles + 255) / 256;
     const bool want8 = can8 && 2.6f * rounds8 < 1.0f * rounds128;
-    const bool big = mode == 256 || (mode != 128 && mode != 8 && tiles256 >= 6 * 256);
     // a 256-row tile spans at most 256 / (Hout*Wout) + 2 images: their bytes must fit the 32-bit lane offsets
     const bool can8c = conv && p.K >= 256 && (long)p.N * p.ldw < (1L << 31) &&
                        (256L / (p.Hout * p.Wout) + 3) * p.Hin * p.Win * p.Cin * 2 < (1L << 31);
@@ -847,9 +710,8 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
         // K = 1024 tile of the 128^2 kernel plus the extra launch costs what the idle CUs of the last round cost.  Not kept.
         GemmParams p8 = p;
         p8.stamp = g_gemm_stamp;
-        static const int epi_env = [] { const char* e = getenv("Q3ASR_GEMM_LDS_EPI"); return e ? atoi(e) : 1; }();
         const long esz = p.out_kind == 1 ? 4 : 2;
-        p8.lds_epi = epi_env && p.N % 8 == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0 && (p.ldo * esz) % 16 == 0 &&
+        p8.lds_epi = p.N % 8 == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0 && (p.ldo * esz) % 16 == 0 &&
                      (p.res_kind == 0 || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
                      (!p.bias || ((uintptr_t)p.bias & 15) == 0);
         static bool attr8 = false;
@@ -864,25 +726,10 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
             // it hides the dispatch and the pipeline fill of every tile after the first, but its epilogue stores must
             // drain before the next tile's counted waits can pass (measured: +8 % at K <= 2048, -2..3 % on long-K or
             // SwiGLU tiles, tools/bench_gemm.py)
-            static const int force = [] { const char* e = getenv("Q3ASR_GEMM_PERSIST"); return e ? atoi(e) : -1; }();
-            const bool persist = force >= 0 ? force != 0 : (p.K <= 2048 && p.act != 2);
+            const bool persist = p.K <= 2048 && p.act != 2;
             const unsigned grid = persist && tiles256 > 256u ? 256u : tiles256;
             hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles256);
         }
-        return;
-    }
-    if (big) {                                                        // measured: 1.17-1.2x on >= 6 tiles per CU, slower below
-        const size_t lds = 2 * 2 * G2_T * 128;
-        static bool attr_set = false;
-        if (!attr_set) {                                     // 128 KiB of dynamic LDS needs the opt-in (once per process)
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)gemm256_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        if (conv) hipLaunchKernelGGL(gemm256_kernel<1>, dim3(tiles256), dim3(512), lds, s, p);
-        else if (fast) hipLaunchKernelGGL((gemm256_kernel<0, true>), dim3(tiles256), dim3(512), lds, s, p);
-        else hipLaunchKernelGGL(gemm256_kernel<0>, dim3(tiles256), dim3(512), lds, s, p);
         return;
     }
     if (conv) hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), 0, s, p);

@@ -94,7 +94,7 @@ class DecodeWorkspace:
     batch as two launch chains that way: measured slower)."""
 
     def __init__(self, cfg: TextDecoderConfig, B: int, max_out: int, device, fp8: bool = False, parent: "DecodeWorkspace" = None,
-                 row0: int = 0):
+                 row0: int = 0, geo4_override: Optional[dict] = None):
         import torch
         i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=device)          # noqa: E731
         bf = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=device)        # noqa: E731
@@ -115,17 +115,13 @@ class DecodeWorkspace:
                                                                                parent.finished[r], parent.max_new[r])
             self.out_tokens, self.logits = parent.out_tokens[r], parent.logits[r]
         self.row_b = torch.arange(B, dtype=torch.int32, device=device)
-        self.h, self.x, self.q, self.att, self.act = bf(B, H), bf(B, H), bf(B, qd), bf(B, qd), bf(B, I)
+        self.h = bf(B, H)
         self.cfg = cfg
         self.MT = ops.mt_of(B)
         rows = 16 * self.MT
         self.x16, self.att16, self.act16 = bf(rows * H), bf(rows * qd), bf(rows * I)     # X16-layout operands
         for t in (self.x16, self.att16, self.act16):
             t.zero_()                                                                    # rows >= B stay zero
-        self.splits = {
-            "qkv": ops.pick_splits(qkvd, H), "o": ops.pick_splits(H, qd),
-            "gu": ops.pick_splits(2 * I, H), "down": ops.pick_splits(H, I),
-        }
         self.geo = {"qkv": ops.gemm_geometry(qkvd, H, fp8=fp8), "o": ops.gemm_geometry(H, qd, fp8=fp8),
                     "down": ops.gemm_geometry(H, I, fp8=fp8), "gu": ops.gemm_geometry(2 * I, H, swiglu=True, fp8=fp8),
                     "head": ops.gemm_geometry(cfg.vocab_size, H, direct=True, fp8=fp8)}
@@ -134,15 +130,13 @@ class DecodeWorkspace:
                      "down": ops.gemm_geometry4(H, I, 0, fp8, B), "gu": ops.gemm_geometry4(2 * I, H, 2, fp8, B),
                      "head": ops.gemm_geometry4(cfg.vocab_size, H, 1, fp8, B)}
 
-        for item in filter(None, os.environ.get("Q3ASR_GEO4", "").split(";")):     # tuning knob: "qkv=2,4,8;down=2,6,8"
-            which, g = item.split("=")
-            self.geo4[which] = tuple(int(v) for v in g.split(","))
+        for which, g in (geo4_override or {}).items():       # tuning knob (tools/tune_decode.py): {"qkv": (2, 4, 8), ...}
+            self.geo4[which] = tuple(int(v) for v in g)
 
         def s4(which, K):
             g = self.geo4[which]
             return K // (32 * g[1] * g[2]) if g else 1
-        n_slab = max(self.splits["qkv"] * qkvd, self.splits["o"] * H, self.splits["gu"] * 2 * I, self.splits["down"] * H,
-                     self.geo["qkv"][0] * qkvd, self.geo["o"][0] * H, self.geo["down"][0] * H,
+        n_slab = max(self.geo["qkv"][0] * qkvd, self.geo["o"][0] * H, self.geo["down"][0] * H,
                      s4("qkv", H) * qkvd, s4("o", qd) * H, s4("down", I) * H)
         self.slab = torch.empty((n_slab * B,), dtype=torch.float32, device=device)
         # batch <= 2 runs the residual + RMSNorm inside the consuming GEMM: second slab buffer and residual stream to ping-pong
@@ -173,8 +167,8 @@ class TextDecoder:
         self.embed_tokens = None
         self._plans: dict = {}
         self._ws: dict = {}
-        self.decode_impl = "v3"      # "v1": row-major weights, X through LDS, separate rope/swiglu kernels (kept for A/B)
-        self.decode_gemm = os.environ.get("Q3ASR_DECODE_GEMM", "sk4")   # "sk4": skinny4 where a geometry fits; "sk3": skinny3 everywhere (A/B)
+        self.decode_gemm = "sk4"     # "sk4": skinny4 where a geometry fits; "sk3": skinny3 everywhere (A/B; Qwen3ASR.from_pretrained(decode_gemm=...))
+        self.geo4_override: dict = {}    # launch geometries by GEMM name (tools/tune_decode.py); applies to workspaces created afterwards
         self.fuse_norm = True        # batch <= 2: residual + RMSNorm inside the consuming qkv GEMM (False: separate launches, A/B; tools/ab_batch1.py)
         self.fuse_norm_gu = True     # ... and inside gate/up too
         self._caches: dict = {}
@@ -357,18 +351,31 @@ class TextDecoder:
         B = len(seq_lens)
         h = embeds.clone()
         pl = self._layers_prefill(h, cache, seq_lens, slots)
-        xl = torch.empty((B, cfg.hidden_size), dtype=torch.bfloat16, device=self.device)
-        ops.rmsnorm(h, w["norm"], xl, B, cfg.hidden_size, cfg.rms_norm_eps, row_idx=pl["last"])
         if logits_out is None:
             logits_out = torch.empty((B, cfg.vocab_size), dtype=torch.bfloat16, device=self.device)
-        self._lm_head(xl, B, logits_out)
+        self._lm_head_rows(h, pl["last"], pl["M"], B, logits_out)
         return logits_out
 
-    def _lm_head(self, x, M, out):
-        cfg = self.config
+    def _lm_head_rows(self, h, rows, n_rows_h: int, M: int, out) -> None:
+        """Final RMSNorm of rows `rows` (int32 [M], device) of h and the tied head (decoder.py:251-252) for M <= 64 rows: the
+        decode step's own kernels (gathered norm straight into the X16 operand layout, then the weight-streaming GEMM over
+        the re-tiled embedding), so the first token's logits come out of the same arithmetic as every later one's."""
+        import torch
+        cfg, w, H = self.config, self.w, self.config.hidden_size
+        fp8 = getattr(self, "weight_dtype", "bf16") != "bf16"
         for m0 in range(0, M, 64):
             mm = min(64, M - m0)
-            ops.skinny_gemm(x[m0:], mm, self.w["embed"], cfg.vocab_size, cfg.hidden_size, 1, None, out[m0:])
+            MT = ops.mt_of(mm)
+            x16 = torch.zeros((16 * MT * H,), dtype=torch.bfloat16, device=self.device)
+            scratch = torch.empty((mm, H), dtype=torch.bfloat16, device=self.device)
+            ops.call("q3asr_embed_norm_x16", ops.ptr(rows[m0:]), ops.ptr(h), int(n_rows_h), ops.ptr(scratch), ops.ptr(w["norm"]), ops.ptr(x16),
+                     mm, H, cfg.rms_norm_eps, ops.sp())
+            g4 = ops.gemm_geometry4(cfg.vocab_size, H, 1, fp8, mm) if self.decode_gemm == "sk4" else None
+            if g4 is not None:
+                ops.skinny4(x16, mm, w["embed16"], cfg.vocab_size, H, 1, *g4, out=out[m0:], scale=w["embed_s"])
+            else:
+                S, waves, rt, ksplit = ops.gemm_geometry(cfg.vocab_size, H, direct=True, fp8=fp8)
+                ops.skinny3(x16, mm, w["embed16"], cfg.vocab_size, H, 1, S, waves, out=out[m0:], rt=rt, ksplit=ksplit, scale=w["embed_s"])
 
     # ------------------------------------------------------------------ decode step (hot path)
     def workspace(self, B: int, max_out: int) -> DecodeWorkspace:
@@ -379,7 +386,8 @@ class TextDecoder:
             if len(mine) > 8:                                # evict this lane's entries only: another lane may be mid-request
                 for k in mine:
                     del self._ws[k]
-            ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device, fp8=getattr(self, "weight_dtype", "bf16") != "bf16")
+            ws = self._ws[key] = DecodeWorkspace(self.config, B, max_out, self.device, fp8=getattr(self, "weight_dtype", "bf16") != "bf16",
+                                                 geo4_override=self.geo4_override)
         return ws
 
     def batch_cache(self, B: int, Lmax: int) -> KVCache:
@@ -399,42 +407,17 @@ class TextDecoder:
 
     def decode_step(self, ws: DecodeWorkspace, cache: KVCache, sampling: dict) -> None:
         """One token for every sequence: embed(cur_tok) -> 28 layers at position pos[b] -> tied head ->
-        sample -> bookkeeping.  ~9 launches per layer, no host interaction (graph-capturable)."""
+        sample -> bookkeeping.  7 launches per layer (5 at batch <= 2), no host interaction (graph-capturable)."""
         cfg, w = self.config, self.w
         B, H, I = ws.B, cfg.hidden_size, cfg.intermediate_size
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
         eps, scale, Lmax = cfg.rms_norm_eps, hd ** -0.5, cache.max_len
-        sp = ws.splits
         layers = w["layers"]
-        if self.decode_impl != "v3" and getattr(self, "fp8_prefill", False):
-            raise NotImplementedError("decode_impl 'v1' reads row-major bf16 weights; weight_dtype='fp8' keeps none (use 'fp8w')")
-        if self.decode_impl == "v3":
-            ops.call("q3asr_embed_norm_x16", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), cfg.vocab_size, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
-                     ops.ptr(ws.x16), B, H, eps, ops.sp())
-            self._layers_decode_v3(ws, cache, ws.pos)
-            self._gemm3(ws, "head", ws.x16, w, "embed", cfg.vocab_size, H, 1, out=ws.logits)
-            self.sample_step(ws, ws.logits, sampling)
-            return
-        ops.call("q3asr_embed_rmsnorm", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), cfg.vocab_size, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
-                 ops.ptr(ws.x), B, H, eps, ops.sp())
-        for li, L in enumerate(layers):
-            self._skinny_slab(ws.x, B, L["wqkv"], qkvd, H, sp["qkv"], ws.slab)
-            ops.call("q3asr_qk_norm_rope_kv", ops.ptr(ws.slab), 1, qkvd, sp["qkv"], B * qkvd, ops.ptr(ws.row_b), ops.ptr(ws.pos),
-                     ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(ws.q), ops.ptr(cache.k[li]),
-                     ops.ptr(cache.v[li]), B, nh, nkv, hd, Lmax, ops.sp())
-            ops.call("q3asr_attn_decode", ops.ptr(ws.q), ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(ws.pos),
-                     ops.ptr(ws.att), B, nh, nkv, hd, Lmax, scale, ops.sp())
-            self._skinny_slab(ws.att, B, L["wo"], H, qd, sp["o"], ws.slab)
-            ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(ws.slab), sp["o"], B * H, ops.ptr(ws.h), ops.ptr(ws.h),
-                     ops.ptr(L["ln2"]), ops.ptr(ws.x), B, H, eps, ops.sp())
-            self._skinny_slab(ws.x, B, L["wgu"], 2 * I, H, sp["gu"], ws.slab)
-            ops.call("q3asr_slab_swiglu", ops.ptr(ws.slab), sp["gu"], B * 2 * I, ops.ptr(ws.act), B, I, ops.sp())
-            self._skinny_slab(ws.act, B, L["wdown"], H, I, sp["down"], ws.slab)
-            nxt = layers[li + 1]["ln1"] if li + 1 < len(layers) else w["norm"]
-            ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(ws.slab), sp["down"], B * H, ops.ptr(ws.h), ops.ptr(ws.h),
-                     ops.ptr(nxt), ops.ptr(ws.x), B, H, eps, ops.sp())
-        ops.skinny_gemm(ws.x, B, w["embed"], cfg.vocab_size, H, 1, None, ws.logits)
+        ops.call("q3asr_embed_norm_x16", ops.ptr(ws.cur_tok), ops.ptr(w["embed"]), cfg.vocab_size, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]),
+                 ops.ptr(ws.x16), B, H, eps, ops.sp())
+        self._layers_decode(ws, cache, ws.pos)
+        self._gemm3(ws, "head", ws.x16, w, "embed", cfg.vocab_size, H, 1, out=ws.logits)
         self.sample_step(ws, ws.logits, sampling)
 
     def _gemm3(self, ws: DecodeWorkspace, which: str, X16, holder: dict, name: str, N, K, epi, out=None, slab=None) -> int:
@@ -463,7 +446,7 @@ class TextDecoder:
                          slab=slab if epi == 0 else None, out=out, rt=rt, ksplit=ksplit, scale=holder[name + "_s"])
         return S
 
-    def _layers_decode_v3(self, ws: DecodeWorkspace, cache: KVCache, pos) -> None:
+    def _layers_decode(self, ws: DecodeWorkspace, cache: KVCache, pos) -> None:
         """7 launches per layer, every GEMM operand in its streaming layout (W16 / X16):
         qkv GEMM (slabs) -> attention with fused QK-norm / RoPE / KV append -> o GEMM (slabs) ->
         residual + RMSNorm -> gate/up GEMM with SwiGLU epilogue -> down GEMM (slabs) -> residual + RMSNorm.
@@ -529,10 +512,6 @@ class TextDecoder:
         self._gemm3(ws, "head", ws.x16, w, "embed", cfg.vocab_size, H, 1, out=ws.logits)
         return 4 * len(w["layers"]) + 1
 
-    def _skinny_slab(self, X, M, W, N, K, splits, slab):
-        # always through the slab (splits may be 1): the consumer kernels read fp32 partials
-        ops.call("q3asr_skinny_gemm", ops.ptr(X), K, M, ops.ptr(W), K, N, K, splits, ops.ptr(slab), None, N, ops.sp())
-
     def sample_step(self, ws: DecodeWorkspace, logits, s: dict) -> None:
         ops.call("q3asr_sample_step", ops.ptr(logits), logits.stride(0), ws.B, self.config.vocab_size, ops.ptr(ws.out_tokens),
                  ws.max_out, ops.ptr(ws.n_gen), ops.ptr(ws.finished), ops.ptr(ws.cur_tok), ops.ptr(ws.pos), ops.ptr(ws.max_new),
@@ -559,7 +538,7 @@ class TextDecoder:
         # (every buffer the captured launches address: K/V blocks AND the attention workspace -- a re-created cache can get
         # its large K/V blocks back from the caching allocator while the small workspace lands elsewhere -- and every switch
         # that changes which launches are recorded)
-        key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.attn_ws.data_ptr(), cache.max_len, self.decode_impl, self.decode_gemm,
+        key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.attn_ws.data_ptr(), cache.max_len, self.decode_gemm,
                bool(self.fuse_norm), bool(self.fuse_norm_gu), tuple(sorted(sampling.items())))
         if ws.graph is not None and ws.graph_key == key:
             ws.graph_uses += 1
@@ -621,10 +600,7 @@ class TextDecoder:
         else:
             raise NotImplementedError("multi-token call with a non-empty cache")
         logits = torch.empty((T, cfg.vocab_size), dtype=torch.bfloat16, device=dev)
-        if T <= 64:
-            self._lm_head(x, T, logits)
-        else:
-            ops.gemm(x, w["embed"], T, cfg.vocab_size, cfg.hidden_size, logits)
+        ops.gemm(x, w["embed"], T, cfg.vocab_size, cfg.hidden_size, logits)      # every position (decoder.py:252), bf16 rows of the tied embedding
         return logits[None]
 
     def _single_step_hidden(self, h, cache: KVCache, off: int):
@@ -633,37 +609,15 @@ class TextDecoder:
         cfg, w = self.config, self.w
         ws = self._api_ws
         if ws is None:
-            ws = self._api_ws = DecodeWorkspace(cfg, 1, 1, self.device)
-        H, I = cfg.hidden_size, cfg.intermediate_size
-        nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
-        eps, scale, Lmax, sp = cfg.rms_norm_eps, hd ** -0.5, cache.max_len, ws.splits
+            ws = self._api_ws = DecodeWorkspace(cfg, 1, 1, self.device, fp8=getattr(self, "weight_dtype", "bf16") != "bf16",
+                                                geo4_override=self.geo4_override)
+        H, eps = cfg.hidden_size, cfg.rms_norm_eps
         ws.pos.fill_(off)
         layers = w["layers"]
-        if self.decode_impl == "v3":
-            ops.call("q3asr_embed_norm_x16", None, ops.ptr(h), 1, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]), ops.ptr(ws.x16), 1, H,
-                     eps, ops.sp())
-            self._layers_decode_v3(ws, cache, ws.pos)
-            return ops.from_x16(ws.x16, 1, ws.MT).contiguous()
-        ws.h.copy_(h)
-        ops.rmsnorm(ws.h, w["layers"][0]["ln1"], ws.x, 1, H, eps)
-        for li, L in enumerate(layers):
-            self._skinny_slab(ws.x, 1, L["wqkv"], qkvd, H, sp["qkv"], ws.slab)
-            ops.call("q3asr_qk_norm_rope_kv", ops.ptr(ws.slab), 1, qkvd, sp["qkv"], qkvd, ops.ptr(ws.row_b), ops.ptr(ws.pos),
-                     ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(ws.q), ops.ptr(cache.k[li]),
-                     ops.ptr(cache.v[li]), 1, nh, nkv, hd, Lmax, ops.sp())
-            ops.call("q3asr_attn_decode", ops.ptr(ws.q), ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(ws.pos),
-                     ops.ptr(ws.att), 1, nh, nkv, hd, Lmax, scale, ops.sp())
-            self._skinny_slab(ws.att, 1, L["wo"], H, qd, sp["o"], ws.slab)
-            ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(ws.slab), sp["o"], H, ops.ptr(ws.h), ops.ptr(ws.h),
-                     ops.ptr(L["ln2"]), ops.ptr(ws.x), 1, H, eps, ops.sp())
-            self._skinny_slab(ws.x, 1, L["wgu"], 2 * I, H, sp["gu"], ws.slab)
-            ops.call("q3asr_slab_swiglu", ops.ptr(ws.slab), sp["gu"], 2 * I, ops.ptr(ws.act), 1, I, ops.sp())
-            self._skinny_slab(ws.act, 1, L["wdown"], H, I, sp["down"], ws.slab)
-            nxt = layers[li + 1]["ln1"] if li + 1 < len(layers) else w["norm"]
-            ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(ws.slab), sp["down"], H, ops.ptr(ws.h), ops.ptr(ws.h),
-                     ops.ptr(nxt), ops.ptr(ws.x), 1, H, eps, ops.sp())
-        return ws.x.clone()
+        ops.call("q3asr_embed_norm_x16", None, ops.ptr(h), 1, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]), ops.ptr(ws.x16), 1, H,
+                 eps, ops.sp())
+        self._layers_decode(ws, cache, ws.pos)
+        return ops.from_x16(ws.x16, 1, ws.MT).contiguous()
 
 
 def load_decoder_weights(decoder: TextDecoder, model_path: str | Path, device: Optional[str] = None,

@@ -107,9 +107,13 @@ class Qwen3ASR:
     @classmethod
     def from_pretrained(cls, model_id_or_path: str | Path, **kwargs) -> "Qwen3ASR":
         """Local model directory (config.json, model.safetensors, tokenizer files) or a Hub repo id
-        (downloaded with snapshot_download(**kwargs); needs network).  Extra keyword ``device``."""
+        (downloaded with snapshot_download(**kwargs); needs network).  Engine keywords, consumed here (everything else goes to
+        snapshot_download as in the reference): ``device``; ``weight_dtype`` "bf16" | "fp8" | "fp8w" (BASELINE.json configs[4]);
+        ``decode_gemm`` "sk4" | "sk3" (decode-step GEMM kernel, A/B); ``use_graph`` (hipGraph decode, default True);
+        ``encoder_precision`` "bf16" | "fp32" (the reference-semantics encoder mode)."""
         device = kwargs.pop("device", None)
         weight_dtype = kwargs.pop("weight_dtype", "bf16")          # "fp8": BASELINE.json configs[4]
+        knobs = {k: kwargs.pop(k) for k in ("decode_gemm", "use_graph", "encoder_precision") if k in kwargs}
         path = Path(model_id_or_path)
         if not path.is_dir():
             from huggingface_hub import snapshot_download
@@ -119,18 +123,33 @@ class Qwen3ASR:
         load_encoder_weights(encoder, path, device)
         decoder = TextDecoder(config.text_decoder)
         load_decoder_weights(decoder, path, device, weight_dtype)
-        return cls(config, encoder, decoder, Tokenizer(path))
+        return cls(config, encoder, decoder, Tokenizer(path))._configure(**knobs)
 
     @classmethod
-    def from_state_dict(cls, config: ModelConfig, state: dict, tokenizer, device=None, weight_dtype: str = "bf16") -> "Qwen3ASR":
-        """Build from in-memory checkpoint tensors (keys as in model.safetensors)."""
+    def from_state_dict(cls, config: ModelConfig, state: dict, tokenizer, device=None, weight_dtype: str = "bf16", **knobs) -> "Qwen3ASR":
+        """Build from in-memory checkpoint tensors (keys as in model.safetensors); `knobs` as in from_pretrained."""
         import torch
         dev = device or f"cuda:{torch.cuda.current_device()}"
         encoder = AudioEncoder(config.audio_encoder)
         encoder.load_state({k[len("audio_tower."):]: v for k, v in state.items() if k.startswith("audio_tower.")}, dev)
         decoder = TextDecoder(config.text_decoder)
         decoder.load_state({k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}, dev, weight_dtype)
-        return cls(config, encoder, decoder, tokenizer)
+        return cls(config, encoder, decoder, tokenizer)._configure(**knobs)
+
+    def _configure(self, decode_gemm: Optional[str] = None, use_graph: Optional[bool] = None,
+                   encoder_precision: Optional[str] = None) -> "Qwen3ASR":
+        """The engine's explicit switches (no environment variables are read anywhere in the package)."""
+        if decode_gemm is not None:
+            if decode_gemm not in ("sk4", "sk3"):
+                raise ValueError(f"decode_gemm must be 'sk4' or 'sk3', got {decode_gemm!r}")
+            self._decoder.decode_gemm = decode_gemm
+        if use_graph is not None:
+            self.use_graph = bool(use_graph)
+        if encoder_precision is not None:
+            if encoder_precision not in ("bf16", "fp32"):
+                raise ValueError(f"encoder_precision must be 'bf16' or 'fp32', got {encoder_precision!r}")
+            self._encoder.precision = encoder_precision
+        return self
 
     # ------------------------------------------------------------------ public API
     def transcribe(self, audio, language: Optional[str] = None, temperature: float = 0.0, top_p: float = 1.0,

@@ -68,23 +68,6 @@ def attn_fwd(Q, q_stride, K, V, kv_seg_off, kv_head_stride, kv_row_stride, O, o_
          ptr(seg_q_start), ptr(seg_len), n_segs, max_len, n_heads, n_kv_heads, head_dim, 1 if causal else 0, scale, sp())
 
 
-def skinny_gemm(X, M, W, N, K, n_splits, slab, out, ldx=None, ldo=None):
-    """n_splits > 1: fp32 partials to `slab` [n_splits][M][N]; n_splits == 1: bf16 `out` [M][ldo]."""
-    call("q3asr_skinny_gemm", ptr(X), ldx or K, M, ptr(W), K, N, K, n_splits, ptr(slab) if n_splits > 1 else None,
-         ptr(out) if n_splits == 1 else None, ldo or N, sp())
-
-
-def pick_splits(N: int, K: int, target_wgs: int = 512) -> int:
-    """Smallest split-K factor (K slice a multiple of 256) that puts >= target_wgs workgroups on the
-    256 CUs; the largest valid one if none reaches it."""
-    tiles = (N + 63) // 64
-    valid = [s for s in range(1, K // 256 + 1) if K % (s * 256) == 0]
-    for s in valid:
-        if tiles * s >= target_wgs:
-            return s
-    return valid[-1]
-
-
 # ---------------------------------------------------------------- decode-step streaming layouts
 def mt_of(M: int) -> int:
     return 1 if M <= 16 else (2 if M <= 32 else 4)

@@ -7,6 +7,8 @@ import torch
 from signals import signal
 
 pytestmark = pytest.mark.gpu
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
 
 # Tolerances (stated, per north_star): encoder features and logits are O(1); the HIP path and the
 # oracle round to bf16 at the same points, so residual differences are float32 summation order
@@ -409,20 +411,24 @@ def test_full_size_batch_invariance_30s(dev, full):
     assert model.generate_tokens(xs[::-1], [10] * 4, "English") == batched[::-1]
 
 
-def test_decode_v1_and_v3_agree(dev, small):
-    """The two decode-step implementations share rounding points: same tokens."""
+def test_decode_gemm_kernels_agree_and_knobs_are_explicit(dev, small):
+    """The skinny4 and skinny3 decode GEMMs share rounding points (tokens agree up to near-ties), selected by an explicit
+    constructor keyword; the package reads no environment variable."""
+    import os
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import synth
     cfg, state, model = small
     x = signal("speechlike", 80000, seed=9)
-    v3 = model.generate_tokens([x], [20], "English")[0]
-    model._decoder.decode_impl = "v1"
-    model._decoder._ws.clear()
-    try:
-        v1 = model.generate_tokens([x], [20], "English")[0]
-    finally:
-        model._decoder.decode_impl = "v3"
-        model._decoder._ws.clear()
-    agree = sum(a == b for a, b in zip(v1, v3))
-    assert v1[0] == v3[0] and agree >= 16
+    sk4 = model.generate_tokens([x], [20], "English")[0]
+    other = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, decode_gemm="sk3", use_graph=False)
+    assert other._decoder.decode_gemm == "sk3" and other.use_graph is False and model._decoder.decode_gemm == "sk4"
+    sk3 = other.generate_tokens([x], [20], "English")[0]
+    agree = sum(a == b for a, b in zip(sk3, sk4))
+    assert sk3[0] == sk4[0] and agree >= 16
+    with pytest.raises(ValueError, match="decode_gemm"):
+        q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, decode_gemm="v1")
+    src = "".join(p.read_text() for p in (ROOT / "qwen3-asr-mlx_amd").glob("*.py") if p.name != "build.py")
+    assert "os.environ" not in src and "getenv" not in "".join(p.read_text() for p in (ROOT / "qwen3-asr-mlx_amd" / "csrc").glob("*.hip"))
 
 
 def test_real_checkpoint_harness_plumbing(dev, tmp_path, capsys):

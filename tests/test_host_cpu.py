@@ -44,7 +44,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert h.q3asr_gemm_bf16(None, 0, None, 0, 1, 1, 1, None, 0, None, 0, 0, 0, None, 0, 0, None, None) == -1
     assert b"null pointer" in h.q3asr_last_error()
     with pytest.raises(ValueError):
-        q._lib.call("q3asr_skinny_gemm", None, 0, 1, None, 0, 64, 256, 1, None, None, 64, None)
+        q._lib.call("q3asr_skinny4_gemm", None, 1, None, None, 64, 256, 0, 2, 2, 8, None, None, 64, None)
 
 
 def test_filterbank_and_prompt_and_splitter_match_fixtures():
@@ -174,11 +174,10 @@ def test_encoder_plan_and_masks_cpu():
 
 def test_decode_split_choice():
     from qwen3_asr_mlx_amd import ops
-    assert ops.pick_splits(4096, 2048) == 8 and ops.pick_splits(12288, 2048) == 4
-    assert ops.pick_splits(2048, 6144) in (12, 24) and ops.pick_splits(151936, 2048) == 1
-    for n, k in ((2048, 2048), (1024, 512), (2048, 1024)):
-        s = ops.pick_splits(n, k)
-        assert k % (s * 256) == 0
+    for (n, k), (tpw, nks, waves) in list(ops._TUNED4.items()) + list(ops._TUNED4_F8.items()):   # skinny4 tables obey their preconditions
+        assert k % (32 * nks * waves) == 0 and (n // 16) % tpw == 0
+    assert ops.gemm_geometry4(151936, 2048, 1) == (2, 8, 8) and ops.gemm_geometry4(2048, 6144, 0, fp8=True) == (2, 6, 8)
+    assert ops.gemm_geometry4(1024, 768, 0) is None                 # K not a multiple of 512: the skinny3 fallback
     assert ops.gemm_geometry(12288, 2048, swiglu=True) == (1, 4, 2, True)
     for (n, k), (S, waves, rt, ks) in ops._TUNED.items():           # the measured table obeys the launch preconditions
         assert k % (32 * S) == 0 and waves in (1, 2, 4) and rt in (1, 2, 4) and (not ks or (k // S) % (32 * waves) == 0)

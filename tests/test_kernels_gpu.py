@@ -192,9 +192,9 @@ def test_gemm_swiglu(dev):
                                    (777, 992, 512),               # ragged N as well (last tile column 224 wide)
                                    (4396, 4096, 1024)])           # 288 tiles: the 8-phase kernel walks two tiles per workgroup
 def test_gemm_kernels_agree_bitwise(dev, M, N, K):
-    """The 128x128 kernel, the 256x256 register-staged kernel and the 256x256 8-phase LDS-DMA kernel accumulate every
-    output in the same order (k ascending, one MFMA chain): bit-identical results, plain, fp32-out and through the
-    epilogues (bias+GELU, bf16 residual, SwiGLU), including ragged M edges."""
+    """The 128x128 kernel and the 256x256 8-phase LDS-DMA kernel accumulate every output in the same order (k ascending, one
+    MFMA chain): bit-identical results, plain, fp32-out and through the epilogues (bias+GELU, bf16 residual, SwiGLU),
+    including ragged M edges -- which is what makes a clip's result independent of the batch it is decoded in."""
     from qwen3_asr_mlx_amd import _lib, ops
     A = rnd((M, K), dev, 40, 1.0)
     W = rnd((N, K), dev, 41, 1.0 / math.sqrt(K))
@@ -209,7 +209,7 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     rm = rm.to(dev)
     outs = {}
     try:
-        for mode in (128, 256, 8):
+        for mode in (128, 8):
             _lib.call("q3asr_gemm_force_kernel", mode)
             o32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
             ops.gemm(A, W, M, N, K, o32, out_fp32=True)
@@ -227,9 +227,8 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     finally:
         _lib.call("q3asr_gemm_force_kernel", 0)
     torch.testing.assert_close(outs[8][0].cpu(), _gemm_ref(A, W), atol=2e-3, rtol=1e-3)
-    for mode in (256, 8):
-        for a, b in zip(outs[128], outs[mode]):
-            assert torch.equal(a, b), mode
+    for a, b in zip(outs[128], outs[8]):
+        assert torch.equal(a, b)
 
 
 def test_gemm_8phase_direct_epilogue_fallback(dev):
@@ -373,7 +372,7 @@ def test_conv3x3s2_implicit_gemm(dev, imgs, H, W_, C):
 
 @pytest.mark.parametrize("imgs,H,W_,C,Co", [(40, 25, 32, 480, 480), (9, 64, 50, 96, 256), (33, 13, 16, 64, 512)])
 def test_conv3x3s2_kernels_agree_bitwise(dev, imgs, H, W_, C, Co):
-    """The implicit-GEMM conv through the 128x128, 256x256 and 8-phase kernels (im2col addresses generated in the DMA's
+    """The implicit-GEMM conv through the 128x128 and the 8-phase kernels (im2col addresses generated in the DMA's
     source address, padding taps and the K tail read from a zero line): identical bits; checked against torch too."""
     from qwen3_asr_mlx_amd import _lib, ops
     x = rnd((imgs, H, W_, C), dev, 53)
@@ -382,7 +381,7 @@ def test_conv3x3s2_kernels_agree_bitwise(dev, imgs, H, W_, C, Co):
     Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
     outs = {}
     try:
-        for mode in (128, 256, 8):
+        for mode in (128, 8):
             _lib.call("q3asr_gemm_force_kernel", mode)
             o = torch.empty((imgs, Ho, Wo, Co), dtype=torch.bfloat16, device=dev)
             ops.conv3x3s2(x, imgs, H, W_, C, ops.conv_weight_chunked(w), Co, b, 1, o)
@@ -391,7 +390,7 @@ def test_conv3x3s2_kernels_agree_bitwise(dev, imgs, H, W_, C, Co):
         _lib.call("q3asr_gemm_force_kernel", 0)
     ref = F.gelu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), b.cpu(), stride=2, padding=1))
     torch.testing.assert_close(outs[8].float().cpu(), bfr(ref.permute(0, 2, 3, 1)), atol=2e-2, rtol=8e-3)
-    assert torch.equal(outs[8], outs[128]) and torch.equal(outs[256], outs[128])
+    assert torch.equal(outs[8], outs[128])
 
 
 # ----------------------------------------------------------------------------- attention
@@ -465,25 +464,6 @@ def test_attn_online_softmax_rescale_branch(dev):
         torch.testing.assert_close(out[:, h * hd: (h + 1) * hd].float().cpu(), bfr(ref), atol=2e-2, rtol=1.6e-2)
 
 
-@pytest.mark.parametrize("B,poss", [(1, [0]), (3, [5, 63, 200]), (2, [408, 535])])
-def test_attn_decode(dev, B, poss):
-    from qwen3_asr_mlx_amd import ops
-    nh, nkv, hd, Lmax = 4, 2, 128, 576
-    q = rnd((B, nh * hd), dev, 80)
-    kc = rnd((B, nkv, Lmax, hd), dev, 81)
-    vc = rnd((B, nkv, Lmax, hd), dev, 82)
-    out = torch.zeros((B, nh * hd), dtype=torch.bfloat16, device=dev)
-    pos = torch.tensor(poss, dtype=torch.int32, device=dev)
-    ops.call("q3asr_attn_decode", ops.ptr(q), ops.ptr(kc), ops.ptr(vc), ops.ptr(pos), ops.ptr(out), B, nh, nkv, hd, Lmax,
-             hd ** -0.5, ops.sp())
-    for b in range(B):
-        L = poss[b] + 1
-        for h in range(nh):
-            ref = _attn_ref(q.float().cpu()[b: b + 1, h * hd: (h + 1) * hd], kc.float().cpu()[b, h // 2, :L],
-                            vc.float().cpu()[b, h // 2, :L], hd ** -0.5, False)
-            torch.testing.assert_close(out[b: b + 1, h * hd: (h + 1) * hd].float().cpu(), bfr(ref), atol=2e-2, rtol=1.6e-2)
-
-
 # ----------------------------------------------------------------------------- rope / kv / embed
 @pytest.mark.parametrize("nh,nkv", [(4, 2), (16, 8), (10, 5)])
 def test_qk_norm_rope_kv_bf16_and_slab(dev, nh, nkv):
@@ -551,60 +531,6 @@ def test_embed_merge(dev):
     ops.call("q3asr_embed_merge", ops.ptr(bad_ids), ops.ptr(bad_src), ops.ptr(E), V, ops.ptr(enc), 5, ops.ptr(out2), 6, H, ops.sp())
     assert torch.equal(out2[0], E[3]) and torch.equal(out2[5], enc[4].to(torch.bfloat16))
     assert not out2[1:5].any()
-
-
-# ----------------------------------------------------------------------------- decode-step kernels
-@pytest.mark.parametrize("M,N,K,S", [(1, 256, 512, 2), (7, 4096, 2048, 8), (32, 2048, 6144, 24), (33, 1024, 512, 1),
-                                     (64, 2048, 2048, 4), (16, 200, 256, 1)])
-def test_skinny_gemm_slabs(dev, M, N, K, S):
-    from qwen3_asr_mlx_amd import ops
-    X = rnd((M, K), dev, 110)
-    W = rnd((N, K), dev, 111, 1.0 / math.sqrt(K))
-    slab = torch.full((S, M, N), float("nan"), dtype=torch.float32, device=dev)
-    ops.call("q3asr_skinny_gemm", ops.ptr(X), K, M, ops.ptr(W), K, N, K, S, ops.ptr(slab), None, N, ops.sp())
-    ref = X.float().cpu() @ W.float().cpu().T
-    torch.testing.assert_close(slab.sum(0).cpu(), ref, atol=2e-3, rtol=1e-3)
-    if S == 1:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        ops.skinny_gemm(X, M, W, N, K, 1, None, out)
-        torch.testing.assert_close(out.float().cpu(), bfr(ref), atol=2e-2, rtol=8e-3)
-
-
-def test_skinny_gemm_identity_layout(dev):
-    from qwen3_asr_mlx_amd import ops
-    K = 512
-    X = torch.eye(K, dtype=torch.bfloat16, device=dev)[:48].contiguous()          # rows e_0..e_47
-    W = (torch.arange(192 * K, dtype=torch.float32).reshape(192, K) % 241 - 120).to(torch.bfloat16).to(dev)
-    out = torch.empty((48, 192), dtype=torch.bfloat16, device=dev)
-    ops.skinny_gemm(X, 48, W, 192, K, 1, None, out)
-    assert torch.equal(out.float().cpu(), W.float().cpu()[:, :48].T)
-
-
-def test_slab_consumers_and_embed_rmsnorm(dev):
-    import oracle.decoder as od
-    from qwen3_asr_mlx_amd import ops
-    M, N, S, I = 5, 2048, 3, 1024
-    slab = rnd((S, M, N), dev, 120, 0.5, torch.float32)
-    h = rnd((M, N), dev, 121)
-    w = rnd((N,), dev, 122) + 1
-    ho, xo = torch.empty_like(h), torch.empty_like(h)
-    ops.call("q3asr_slab_residual_rmsnorm", ops.ptr(slab), S, M * N, ops.ptr(h), ops.ptr(ho), ops.ptr(w), ops.ptr(xo), M, N, 1e-6, ops.sp())
-    tot = (slab[0] + slab[1] + slab[2]).cpu()
-    href = bfr(bfr(tot) + h.float().cpu())
-    assert torch.equal(ho.float().cpu(), href)
-    torch.testing.assert_close(xo.float().cpu(), od.rms_norm(href, w.float().cpu(), 1e-6), atol=0, rtol=8e-3)
-    sl2 = rnd((S, M, 2 * I), dev, 123, 0.7, torch.float32)
-    act = torch.empty((M, I), dtype=torch.bfloat16, device=dev)
-    ops.call("q3asr_slab_swiglu", ops.ptr(sl2), S, M * 2 * I, ops.ptr(act), M, I, ops.sp())
-    t2 = (sl2[0] + sl2[1] + sl2[2]).cpu().reshape(M, I // 16, 2, 16)
-    g, u = bfr(t2[:, :, 0].reshape(M, I)), bfr(t2[:, :, 1].reshape(M, I))
-    torch.testing.assert_close(act.float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=1e-3, rtol=8e-3)
-    E = rnd((50, N), dev, 124)
-    tok = torch.tensor([3, 49, 0, 3, 7], dtype=torch.int32, device=dev)
-    ops.call("q3asr_embed_rmsnorm", ops.ptr(tok), ops.ptr(E), 50, ops.ptr(ho), ops.ptr(w), ops.ptr(xo), M, N, 1e-6, ops.sp())
-    assert torch.equal(ho, E[tok.long()])
-    torch.testing.assert_close(xo.float().cpu(), od.rms_norm(E[tok.long()].float().cpu(), w.float().cpu(), 1e-6), atol=0, rtol=8e-3)
-
 
 
 # ----------------------------------------------------------------------------- decode step in streaming layouts (W16 / X16)
@@ -790,7 +716,8 @@ def test_slab_resnorm_and_embed_norm_x16(dev, M, N, S):
                                               (5, [255, 1023, 1024, 2047, 2900], 3, 3072), (40, None, 2, 1920)])
 def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
     """Fused prologue (slab input, X16 output, 1024-token chunks merged by the last workgroup to arrive) ==
-    q3asr_qk_norm_rope_kv followed by q3asr_attn_decode; the workspace is left ready for the next launch."""
+    q3asr_qk_norm_rope_kv (the prefill kernel, slab form) followed by a float32 softmax attention over the cache in torch;
+    the workspace is left ready for the next launch, and the result does not depend on how many chunks a workgroup sweeps."""
     from qwen3_asr_mlx_amd import _lib, ops
     nh, nkv, hd = 4, 2, 128
     qkvd = (nh + 2 * nkv) * hd
@@ -806,9 +733,13 @@ def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
     q = torch.zeros((B, nh * hd), dtype=torch.bfloat16, device=dev)
     ops.call("q3asr_qk_norm_rope_kv", ops.ptr(parts), 1, qkvd, S, B * qkvd, ops.ptr(rb), ops.ptr(pos), ops.ptr(qn), ops.ptr(kn),
              ops.ptr(inv), 1e-6, ops.ptr(q), ops.ptr(kc1), ops.ptr(vc1), B, nh, nkv, hd, Lmax, ops.sp())
-    ref = torch.zeros((B, nh * hd), dtype=torch.bfloat16, device=dev)
-    ops.call("q3asr_attn_decode", ops.ptr(q), ops.ptr(kc1), ops.ptr(vc1), ops.ptr(pos), ops.ptr(ref), B, nh, nkv, hd, Lmax,
-             hd ** -0.5, ops.sp())
+    ref = torch.zeros((B, nh * hd), dtype=torch.float32)
+    for b in range(B):
+        L = poss[b] + 1
+        for h in range(nh):
+            ref[b, h * hd: (h + 1) * hd] = _attn_ref(q.float().cpu()[b: b + 1, h * hd: (h + 1) * hd], kc1.float().cpu()[b, h // 2, :L],
+                                                      vc1.float().cpu()[b, h // 2, :L], hd ** -0.5, False)[0]
+    ref = bfr(ref).to(dev)
     MT = ops.mt_of(B)
     nbytes = _lib.load().q3asr_attn_decode_fused_workspace(B, nkv, Lmax)
     assert nbytes == 4 * (B * nkv * ((Lmax + 1023) // 1024) * 260 + B * nkv)   # ADF_CHUNK = 1024
@@ -822,20 +753,20 @@ def test_attn_decode_fused_equals_separate_kernels(dev, B, poss, S, Lmax):
         assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
         outs.append(ops.from_x16(o16, B))
         assert int(wsp.view(torch.int32)[-B * nkv:].abs().sum()) == 0            # arrival counters back at zero
-    # same maths; the partial-merge grouping differs (32-key MFMA tiles per wave, chunk merge)
-    torch.testing.assert_close(outs[0].float(), ref.float(), atol=1e-2, rtol=8e-3)
+    # same maths: bf16 probabilities in 32-key MFMA tiles, per-wave and per-chunk partials merged in a fixed order
+    torch.testing.assert_close(outs[0].float(), ref.float(), atol=2e-2, rtol=1.6e-2)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])      # arrival order does not matter
-    # the lane-group dot-product formulation of the same kernel agrees too
+    # any number of chunks per workgroup gives the same bits (per-chunk partials merged in chunk order)
     try:
-        _lib.call("q3asr_attn_decode_force_valu", 1)
-        kc3, vc3 = kc0.clone(), vc0.clone()
-        o16 = torch.zeros((nh * hd // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
-        ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
-                 ops.ptr(kc3), ops.ptr(vc3), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
+        for n_chunks in (1, 2):
+            _lib.call("q3asr_attn_decode_set_chunks_per_wg", n_chunks)
+            kc3, vc3 = kc0.clone(), vc0.clone()
+            o16 = torch.zeros((nh * hd // 32, MT, 64, 8), dtype=torch.bfloat16, device=dev)
+            ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
+                     ops.ptr(kc3), ops.ptr(vc3), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
+            assert torch.equal(kc3, kc1) and torch.equal(vc3, vc1) and torch.equal(ops.from_x16(o16, B), outs[0])
     finally:
-        _lib.call("q3asr_attn_decode_force_valu", 0)
-    assert torch.equal(kc3, kc1) and torch.equal(vc3, vc1)
-    torch.testing.assert_close(ops.from_x16(o16, B).float(), ref.float(), atol=1e-2, rtol=8e-3)
+        _lib.call("q3asr_attn_decode_set_chunks_per_wg", 0)
 
 
 def test_attn_decode_fused_is_independent_of_batch_and_capacity(dev):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """K sweep of q3asr_gemm_bf16 at the encoder's M (12,480 rows): separates the per-tile fixed cost (pipeline fill, epilogue,
 round quantisation) from the main-loop rate.  Usage: python3 tools/bench_gemm_k.py [rounds]
-(Q3ASR_GEMM_PERSIST=0|1 pins the persistent tile loop of the 8-phase kernel.)"""
+"""
 import sys
 from pathlib import Path
 

@@ -30,12 +30,6 @@ for step in "$@"; do
     tests_all)    run 1100 $O/${TAG}_tests_all.log python3 -m pytest $R/tests -m gpu -q -x ; tail -5 $O/${TAG}_tests_all.log ;;
     bench)        run 600 $O/${TAG}_bench.err python3 $R/bench.py --steps 20 --warmup 3 ; grep '^{' $O/${TAG}_bench.err > $O/${TAG}_bench.json; grep -v '^{' $O/${TAG}_bench.err | tail -25 ;;
     benchq)       run 400 $O/${TAG}_benchq.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchq.err > $O/${TAG}_benchq.json; grep -v '^{' $O/${TAG}_benchq.err | tail -12 ;;
-    benchq_sk3)   Q3ASR_DECODE_GEMM=sk3 run 400 $O/${TAG}_benchq_sk3.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchq_sk3.err > $O/${TAG}_benchq_sk3.json; grep -v '^{' $O/${TAG}_benchq_sk3.err | tail -12 ;;
-    benchq_geo)   for g in ${Q3ASR_GEO_LIST:-"o=2,4,8" "qkv=2,2,8"}; do
-                      echo "Q3ASR_GEO4=$g" | tee -a $O/${TAG}_steps.log
-                      Q3ASR_GEO4="$g" run 400 $O/${TAG}_benchq_geo.err python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipeline --no-extra-configs
-                      grep -E "timed step|batch-1|stages" $O/${TAG}_benchq_geo.err | tail -3
-                  done ;;
     benchf8)      run 400 $O/${TAG}_benchf8.err python3 $R/bench.py --steps 5 --warmup 2 --weights fp8 --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchf8.err > $O/${TAG}_benchf8.json; grep -v '^{' $O/${TAG}_benchf8.err | tail -8
                   run 400 $O/${TAG}_benchf8w.err python3 $R/bench.py --steps 5 --warmup 2 --weights fp8w --no-cpu-baseline --no-pipeline --no-extra-configs ; grep '^{' $O/${TAG}_benchf8w.err > $O/${TAG}_benchf8w.json; grep -v '^{' $O/${TAG}_benchf8w.err | tail -8 ;;
     rehearse2)    Q3ASR_BENCH_REHEARSE=1 run 500 $O/${TAG}_rehearse2.err python3 $R/bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline ; grep '^{' $O/${TAG}_rehearse2.err > $O/${TAG}_rehearse2.json; grep -v '^{' $O/${TAG}_rehearse2.err | tail -12 ;;
@@ -69,7 +63,7 @@ for step in "$@"; do
     bench_pmc)    echo "bench_pmc: refused -- the full bench under rocprofv3 --pmc aborts in the profiler after ~3.3e5 dispatch records (DESIGN.md section 2); use bench_pmc16 or tools/pmc_step.sh" ;;
     stamps)       run 300 $O/${TAG}_stamps.log python3 $R/tools/gemm_stamps.py ; cat $O/${TAG}_stamps.log ;;
     gemmk)        run 300 $O/${TAG}_gemmk.log python3 $R/tools/bench_gemm_k.py 5 ; cat $O/${TAG}_gemmk.log
-                  Q3ASR_GEMM_PERSIST=0 run 300 $O/${TAG}_gemmk_np.log python3 $R/tools/bench_gemm_k.py 5 ; cat $O/${TAG}_gemmk_np.log ;;
+                  ;;
     bench_pmc16)  rm -rf $O/${TAG}_bench_pmc16; run 600 $O/${TAG}_bench_pmc16.log rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_bench_pmc16 -- python3 $R/bench.py --steps 1 --warmup 1 --ndec 16 --no-cpu-baseline --no-pipeline --no-extra-configs
                   find $O/${TAG}_bench_pmc16 -name '*.csv' -size +1M -delete; tail -12 $O/${TAG}_bench_pmc16.log ;;
     stage)        run 300 $O/${TAG}_stage.log python3 $R/tools/stage_profile.py 32 30 $O/${TAG}_stage.json ; cat $O/${TAG}_stage.log ;;
