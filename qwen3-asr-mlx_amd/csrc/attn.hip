@@ -43,8 +43,12 @@ struct AttnParams {
     float scale;
 };
 
+// Occupancy: 3 workgroups per CU (round 3; the compiler's free choice was 170 VGPRs = 2): 86-93 -> 76-77 us per prefill layer at
+// 32 x 408 tokens.  Measured beside it and not kept: both query heads of a kv head in one 512-thread workgroup (K/V tile fetched
+// and written to LDS once for two heads, bit-identical): 76.0 vs 77.0 us -- staging is not what a tile costs; a wave's serial
+// QK^T -> softmax (~170 VALU per 32 MFMAs) -> PV chain is, at three waves per SIMD.
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KV_TILE * HD * 2];
     char* sK = smem;
     char* sV = smem + KV_TILE * HD * 2;
