@@ -53,12 +53,14 @@ for step in "$@"; do
     bench_gemm)   run 400 $O/${TAG}_bench_gemm.log python3 $R/tools/bench_gemm.py ${BENCH_GEMM_ARGS:-5 8,2} ; cat $O/${TAG}_bench_gemm.log ;;
     tests_gemm)   run 600 $O/${TAG}_tests_gemm.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k gemm ; tail -8 $O/${TAG}_tests_gemm.log ;;
     admit_cost)   run 300 $O/${TAG}_admit_cost.log python3 $R/tools/admit_cost.py ; grep "k=" $O/${TAG}_admit_cost.log ;;
+    tests_attn)   run 600 $O/${TAG}_tests_attn.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k attn ; tail -5 $O/${TAG}_tests_attn.log ;;
     finite)       run 300 $O/${TAG}_finite.log python3 $R/tools/pmc_probe.py finite,step,graph4,batch1 ; grep probe $O/${TAG}_finite.log | tail -12 ;;
     probe_batch1) prof probe_batch1 batch1 --pmc FETCH_SIZE --kernel-trace ;;
     probe_graph)  prof probe_graph graph --pmc FETCH_SIZE --kernel-trace ;;
     probe_graph4) prof probe_graph4 graph4 --pmc FETCH_SIZE --kernel-trace ;;
     probe_regraph) prof probe_regraph regraph --pmc FETCH_SIZE --kernel-trace ;;
     bench_stats)  rm -rf $O/${TAG}_bench_stats; run 600 $O/${TAG}_bench_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_bench_stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-extra-configs
+                  python3 $R/tools/request_gaps.py $(find $O/${TAG}_bench_stats -name '*kernel_trace.csv') > $O/${TAG}_request_gaps.txt 2>&1; cat $O/${TAG}_request_gaps.txt
                   find $O/${TAG}_bench_stats -name '*kernel_trace.csv' -delete; find $O/${TAG}_bench_stats -name '*.csv' -size +20M -delete
                   find $O/${TAG}_bench_stats -name '*kernel_stats.csv' -exec head -16 {} \; ; grep '^{' $O/${TAG}_bench_stats.log | tail -1 | cut -c1-300 ;;
     bench_pmc)    echo "bench_pmc: refused -- the full bench under rocprofv3 --pmc aborts in the profiler after ~3.3e5 dispatch records (DESIGN.md section 2); use bench_pmc16 or tools/pmc_step.sh" ;;
