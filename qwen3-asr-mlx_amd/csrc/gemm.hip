@@ -45,8 +45,8 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + (
 
 // Epilogue shared by both GEMM kernels.  A lane holds, for accumulator tile (j, i): output row
 // m = m_base + 16 i + li and the 4 consecutive columns n = n_base + 16 j + 4 g + r.
-template <int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n_base, int n0, int wn,
+template <int MI, int NJ = 4>   // NJ: 16-column tiles per wave (4: 64 columns; 2: the 64x64-tile kernel's 32)
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NJ][MI], int m_base, int n_base, int n0, int wn,
                                               int g, int li) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -60,10 +60,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         const long rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
         if (p.act == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {
+            for (int j = 0; j < NJ; j += 2) {
                 const int n_in = n_base + j * 16 + 4 * g;            // gate rows; up rows are n_in + 16
                 if (n_in >= p.N) continue;
-                const int n_out = (n0 >> 1) + wn * 32 + (j >> 1) * 16 + 4 * g;
+                const int n_out = (n0 >> 1) + wn * (8 * NJ) + (j >> 1) * 16 + 4 * g;
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -76,7 +76,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             continue;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int n = n_base + j * 16 + 4 * g;
             if (n >= p.N) continue;
             f32x4 v = acc[j][i];
@@ -344,14 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    if constexpr (FAST) Q3_LOAD_FAST(0) else load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            if constexpr (FAST) Q3_LOAD_FAST((kt + 1) * BK) else load_tile((kt + 1) * BK);
-        }
+    auto compute_tile = [&](int buf) {
         const char* sa = smem + buf * (2 * BM * BK * 2);
         const char* sw = sa + BM * BK * 2;
 #pragma unroll
@@ -369,11 +362,159 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int i = 0; i < 4; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+    if constexpr (FAST) {
+        // Two K tiles in flight in registers (round 3): on a grid of at most one round a workgroup has no neighbour whose MFMAs
+        // hide its loads, and with one tile in flight the loop ran at a load latency per K tile (prefill down at 4 clips, 208
+        // tiles, K = 6,144: 77 us).  Loads are unconditional (K tile clamped to the last one) so the counted vmcnt waits stay exact.
+        u32x4 rb[4], rv[4];                                                   // the second register set
+#define Q3_LOAD_FAST2(K0)                                                                     \
+    {                                                                                         \
+        const char* pa_ = reinterpret_cast<const char*>(p.A) + (long)(K0) * 2;                \
+        const char* pw_ = reinterpret_cast<const char*>(p.W) + (long)(K0) * 2;                \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                       \
+            rb[q] = *reinterpret_cast<const u32x4*>(pa_ + fa_off[q]);                         \
+            rv[q] = *reinterpret_cast<const u32x4*>(pw_ + fw_off[q]);                         \
+        }                                                                                     \
+    }
+        auto store_tile2 = [&](int buf) {
+            char* sa = smem + buf * (2 * BM * BK * 2);
+            char* sw = sa + BM * BK * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = lrow + 32 * q;
+                *reinterpret_cast<u32x4*>(sa + lds_off(r, slot)) = rb[q];
+                *reinterpret_cast<u32x4*>(sw + lds_off(r, slot)) = rv[q];
+            }
+        };
+        Q3_LOAD_FAST(0)
+        Q3_LOAD_FAST2(min(1, nk - 1) * BK)
+        store_tile(0);
         __syncthreads();
+        int kt = 0;
+        for (; kt + 2 <= nk; kt += 2) {                                      // set (ra, rw) holds even K tiles, (rb, rv) odd ones
+            Q3_LOAD_FAST(min(kt + 2, nk - 1) * BK)
+            __builtin_amdgcn_sched_barrier(0);                               // the scheduler otherwise sinks the loads below the
+            compute_tile(0);                                                  // LDS stores of the other set (one tile in flight again)
+            store_tile2(1);
+            __syncthreads();
+            Q3_LOAD_FAST2(min(kt + 3, nk - 1) * BK)
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(1);
+            store_tile(0);
+            __syncthreads();
+        }
+        if (kt < nk) compute_tile(0);
+#undef Q3_LOAD_FAST2
+    } else {
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile((kt + 1) * BK);
+            compute_tile(buf);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     gemm_epilogue<4>(p, acc, m0 + wm * 64, n0 + wn * 64, n0, wn, g, li);
+}
+
+// ---------------------------------------------------------------------------
+// 64x64x64 tiles for GEMMs whose 128^2 grid cannot cover the chip (round 3): a single 30 s clip is M = 390 / 408 rows, and
+// every output keeps ONE k-ascending MFMA chain (no split-K: the same utterance must give the same bits alone and inside
+// a batch of 32), so the only way to put a one-clip `down` projection (N = 2,048, K = 6,144: 64 workgroups of 128^2) on more
+// than a quarter of the CUs is a smaller tile: 224 workgroups of 64^2.  Register-staged, XOR-swizzled, double-buffered LDS like
+// gemm_bf16_kernel (4 waves, each 32 x 32 = 2 x 2 MFMA tiles), same accumulation order, same bits.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm64_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * BK * 2];   // A0 | W0 | A1 | W1, 8 KB each
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + 63) / 64, tiles_m = (p.M + 63) / 64;
+    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    const int group = GROUP_M * tiles_n;
+    const int first_m = (t / group) * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int m0 = (first_m + (int)(t % group) % gm) * 64;
+    const int n0 = ((int)(t % group) / gm) * 64;
+    // loader: 2 A slots and 2 W slots (16 B each) per thread and K tile; edge rows clamped (their outputs are masked)
+    const int slot = tid & 7, lrow = tid >> 3;
+    unsigned fa_off[2], fw_off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        fa_off[q] = (unsigned)(((long)min(m0 + lrow + 32 * q, p.M - 1) * p.lda + slot * 8) * 2);
+        fw_off[q] = (unsigned)(((long)min(n0 + lrow + 32 * q, p.N - 1) * p.ldw + slot * 8) * 2);
+    }
+    // Register staging G64_D K tiles deep: a workgroup is alone on its CU (the grid is at most one round), so nothing but its
+    // own loads in flight hides the ~1 us of a global load; with one tile in flight the loop ran at that latency per K tile
+    // (one clip's down projection, 96 K tiles: 48 us), with four the loads of tiles kt+1..kt+4 overlap the MFMAs of tile kt.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int G64_D = 4;
+    u32x4 ra[G64_D][2], rw[G64_D][2];
+    const int nk = p.K / BK;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+    f32x4 acc[2][2];   // [j: n tile][i: m tile]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define G64_LOAD(set, kt_)                                                                      \
+    do {                                                                                        \
+        const char* pa_ = reinterpret_cast<const char*>(p.A) + (long)(kt_) * (BK * 2);          \
+        const char* pw_ = reinterpret_cast<const char*>(p.W) + (long)(kt_) * (BK * 2);          \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                         \
+            ra[set][q] = *reinterpret_cast<const u32x4*>(pa_ + fa_off[q]);                      \
+            rw[set][q] = *reinterpret_cast<const u32x4*>(pw_ + fw_off[q]);                      \
+        }                                                                                       \
+    } while (0)
+#define G64_STORE(set, buf_)                                                                    \
+    do {                                                                                        \
+        char* sa_ = smem + (buf_) * (2 * 64 * BK * 2);                                          \
+        char* sw_ = sa_ + 64 * BK * 2;                                                          \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                         \
+            const int r = lrow + 32 * q;                                                        \
+            *reinterpret_cast<u32x4*>(sa_ + lds_off(r, slot)) = ra[set][q];                     \
+            *reinterpret_cast<u32x4*>(sw_ + lds_off(r, slot)) = rw[set][q];                     \
+        }                                                                                       \
+    } while (0)
+    // Every step issues its loads unconditionally (K tile index clamped to the last one: at most G64_D redundant tiles per
+    // workgroup), so the compiler's counted vmcnt waits stay exact; behind a uniform `if` it falls back to vmcnt(0).
+#define G64_STEP(d, kt)                                                                         \
+    do {                                                                                        \
+        G64_LOAD(d, min((kt) + G64_D, nk - 1));          /* set d went to LDS one step ago */   \
+        const char* sa = smem + ((d) & 1) * (2 * 64 * BK * 2);                                  \
+        const char* sw = sa + 64 * BK * 2;                                                      \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                      \
+            bf16x8 wf[2], af[2];                                                                \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+                wf[j] = *reinterpret_cast<const bf16x8*>(sw + lds_off(wn * 32 + j * 16 + li, kk * 4 + g)); \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                       \
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * 32 + i * 16 + li, kk * 4 + g)); \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                                   \
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0); \
+        }                                                                                       \
+        G64_STORE(((d) + 1) % G64_D, ((d) + 1) & 1);     /* K tile kt + 1 (a clamped copy after the last) */ \
+        __syncthreads();                                                                        \
+    } while (0)
+#pragma unroll
+    for (int d = 0; d < G64_D; ++d) G64_LOAD(d, min(d, nk - 1));
+    G64_STORE(0, 0);
+    __syncthreads();
+    int kt0 = 0;
+    for (; kt0 + G64_D <= nk; kt0 += G64_D) {           // register set d holds K tile kt0 + d (G64_D is even: LDS buffer = d & 1)
+        G64_STEP(0, kt0); G64_STEP(1, kt0 + 1); G64_STEP(2, kt0 + 2); G64_STEP(3, kt0 + 3);
+    }
+    if (kt0 < nk) { G64_STEP(0, kt0); }                  // K % 256 != 0: up to three more tiles
+    if (kt0 + 1 < nk) { G64_STEP(1, kt0 + 1); }
+    if (kt0 + 2 < nk) { G64_STEP(2, kt0 + 2); }
+#undef G64_STEP
+#undef G64_LOAD
+#undef G64_STORE
+    gemm_epilogue<2, 2>(p, acc, m0 + wm * 32, n0 + wn * 32, n0, wn, g, li);
 }
 
 #define G2_T 256
@@ -678,7 +819,7 @@ static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_s
 extern "C" int q3asr_gemm_set_stamp(void* buf) { g_gemm_stamp = (unsigned long long*)buf; return 0; }
 
 extern "C" int q3asr_gemm_force_kernel(int mode) {
-    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 8, "gemm_force_kernel: mode %d (0 auto, 128, 8 = 8-phase)", mode);
+    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 8 || mode == 64, "gemm_force_kernel: mode %d (0 auto, 64, 128, 8 = 8-phase)", mode);
     g_gemm_mode = mode;
     return 0;
 }
@@ -730,6 +871,14 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
             const unsigned grid = persist && tiles256 > 256u ? 256u : tiles256;
             hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles256);
         }
+        return;
+    }
+    // a 128^2 grid that leaves CUs idle: 64^2 tiles (one clip: M = 390 / 408 rows; small admission groups of the front door).
+    // Measured (tools/bench_gemm_small.py, profiles/r03_gemm_small.txt): one clip's prefill o 27.0 -> 13.2 us, down 72.5 -> 48.0,
+    // qkv 27.5 -> 18.8, encoder fc2 49.7 -> 32.6; a win up to 168 128^2-tiles, a tie at 208-224, a loss above.
+    const unsigned tiles64 = (unsigned)((p.M + 63) / 64) * (unsigned)((p.N + 63) / 64);
+    if (fast && (mode == 64 || (mode == 0 && tiles <= 176u))) {
+        hipLaunchKernelGGL(gemm64_kernel, dim3(tiles64), dim3(256), 0, s, p);
         return;
     }
     if (conv) hipLaunchKernelGGL(gemm_bf16_kernel<1>, dim3(tiles), dim3(256), 0, s, p);

@@ -190,9 +190,10 @@ def test_gemm_swiglu(dev):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 384), (1000, 768, 1024), (2050, 1280, 2048), (515, 256, 6144),
                                    (777, 992, 512),               # ragged N as well (last tile column 224 wide)
-                                   (4396, 4096, 1024)])           # 288 tiles: the 8-phase kernel walks two tiles per workgroup
+                                   (4396, 4096, 1024),            # 288 tiles: the 8-phase kernel walks two tiles per workgroup
+                                   (70, 128, 64), (130, 192, 192)])   # fewer K tiles than the 64^2 kernel keeps in flight (8-phase n/a: 128^2 twice)
 def test_gemm_kernels_agree_bitwise(dev, M, N, K):
-    """The 128x128 kernel and the 256x256 8-phase LDS-DMA kernel accumulate every output in the same order (k ascending, one
+    """The 64x64, the 128x128 and the 256x256 8-phase LDS-DMA kernel accumulate every output in the same order (k ascending, one
     MFMA chain): bit-identical results, plain, fp32-out and through the epilogues (bias+GELU, bf16 residual, SwiGLU),
     including ragged M edges -- which is what makes a clip's result independent of the batch it is decoded in."""
     from qwen3_asr_mlx_amd import _lib, ops
@@ -209,7 +210,7 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     rm = rm.to(dev)
     outs = {}
     try:
-        for mode in (128, 8):
+        for mode in (128, 8, 64):
             _lib.call("q3asr_gemm_force_kernel", mode)
             o32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
             ops.gemm(A, W, M, N, K, o32, out_fp32=True)
@@ -227,8 +228,9 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     finally:
         _lib.call("q3asr_gemm_force_kernel", 0)
     torch.testing.assert_close(outs[8][0].cpu(), _gemm_ref(A, W), atol=2e-3, rtol=1e-3)
-    for a, b in zip(outs[128], outs[8]):
-        assert torch.equal(a, b)
+    for mode in (8, 64):
+        for a, b in zip(outs[128], outs[mode]):
+            assert torch.equal(a, b), mode
 
 
 def test_gemm_8phase_direct_epilogue_fallback(dev):
