@@ -54,6 +54,8 @@ for step in "$@"; do
     tests_gemm)   run 600 $O/${TAG}_tests_gemm.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k gemm ; tail -8 $O/${TAG}_tests_gemm.log ;;
     admit_cost)   run 300 $O/${TAG}_admit_cost.log python3 $R/tools/admit_cost.py ; grep "k=" $O/${TAG}_admit_cost.log ;;
     tests_attn)   run 600 $O/${TAG}_tests_attn.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k attn ; tail -5 $O/${TAG}_tests_attn.log ;;
+    serve)        run 500 $O/${TAG}_serve32.log python3 $R/tools/bench_serve.py 32 25,60,90,120 6 ; tail -1 $O/${TAG}_serve32.log > $O/${TAG}_serve32.json; grep offered $O/${TAG}_serve32.log | cut -c1-200
+                  run 400 $O/${TAG}_serve64.log python3 $R/tools/bench_serve.py 64 90,130 6 ; tail -1 $O/${TAG}_serve64.log > $O/${TAG}_serve64.json; grep offered $O/${TAG}_serve64.log | cut -c1-200 ;;
     gemm_small)   run 300 $O/${TAG}_gemm_small.log python3 $R/tools/bench_gemm_small.py ; grep "k=" $O/${TAG}_gemm_small.log ;;
     finite)       run 300 $O/${TAG}_finite.log python3 $R/tools/pmc_probe.py finite,step,graph4,batch1 ; grep probe $O/${TAG}_finite.log | tail -12 ;;
     probe_batch1) prof probe_batch1 batch1 --pmc FETCH_SIZE --kernel-trace ;;
