@@ -262,22 +262,31 @@ class Qwen3ASR:
             for j, t in zip(sel, toks):
                 texts[j] = self._decode_output(t)
 
-        n_lanes = min(self.lanes, len(batches))
-        if n_lanes <= 1:
-            for bi in range(len(batches)):
+        self._run_batches(len(batches), run)
+        return texts
+
+    def _run_batches(self, n: int, run) -> None:
+        """run(bi) for every bi in range(n).  Several batches: `lanes` of them in flight (one decodes, latency-bound, while
+        another runs its MFMA-bound encoder and prefill); each worker thread owns a lane of the decoder and a stream, which
+        first waits for whatever the caller's stream had queued (device-resident inputs)."""
+        n_lanes = min(self.lanes, n)
+        dev = self._decoder.device if self._decoder is not None else None
+        if n_lanes <= 1 or dev is None or dev.type != "cuda":
+            for bi in range(n):
                 run(bi)
-            return texts
-        # several batches: keep `lanes` of them in flight (one decodes, latency-bound, while another runs its MFMA-bound
-        # encoder and prefill); each worker thread owns a lane of the decoder and a stream
+            return
         import torch
         from .decoder import set_lane
-        dev = self._decoder.device
-        nxt, errs, lock = iter(range(len(batches))), [], threading.Lock()
+        nxt, errs, lock = iter(range(n)), [], threading.Lock()
+        with torch.cuda.device(dev):
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
 
         def worker(lane: int) -> None:
             try:
                 set_lane(lane)
                 with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    torch.cuda.current_stream().wait_event(ready)
                     while not errs:
                         with lock:
                             bi = next(nxt, None)
@@ -295,7 +304,6 @@ class Qwen3ASR:
             th.join()
         if errs:
             raise errs[0]
-        return texts
 
     def _run_jobs_continuous(self, jobs, order, lang, temperature, top_p, top_k, repetition_penalty, repetition_context_size) -> list[str]:
         """More jobs than decode rows: every lane takes every n-th job (longest first), encodes its share in batches and
@@ -369,18 +377,25 @@ class Qwen3ASR:
     def generate_tokens_packed(self, audio, lens: Sequence[int], max_tokens: Sequence[int], lang: str, temperature=0.0,
                                top_p=1.0, top_k=0, repetition_penalty=1.2, repetition_context_size=100, seed=None) -> list[list[int]]:
         """Any number of utterances as ONE padded fp32 tensor [n][Lmax] already on the device (what `dist.run_sharded`
-        hands each rank): walked in batches of MAX_BATCH rows, no host copy of the audio."""
+        hands each rank): walked in batches of MAX_BATCH rows (`lanes` of them in flight), no host copy of the audio."""
         import torch
         dev = self._decoder.device if self._decoder is not None else None
-        out: list[list[int]] = []
-        for s0 in range(0, len(lens), self.MAX_BATCH):
+        starts = list(range(0, len(lens), self.MAX_BATCH))
+        parts: list = [None] * len(starts)
+
+        def run(bi: int) -> None:
+            s0 = starts[bi]
             part = [int(n) for n in lens[s0: s0 + self.MAX_BATCH]]
             rows = audio[s0: s0 + len(part)]
             lens_dev = torch.tensor(part, dtype=torch.int32).to(dev, non_blocking=True)
             sd = None if seed is None else int(seed) + s0
-            out += self.generate_tokens_device(rows, lens_dev, part, list(max_tokens[s0: s0 + len(part)]), lang, temperature, top_p,
-                                               top_k, repetition_penalty, repetition_context_size, sd)
-        return out
+            parts[bi] = self.generate_tokens_device(rows, lens_dev, part, list(max_tokens[s0: s0 + len(part)]), lang, temperature, top_p,
+                                                    top_k, repetition_penalty, repetition_context_size, sd)
+
+        if temperature and seed is None and len(starts) > 1:
+            seed = _next_seed()                               # fixed before any thread runs: the draws do not depend on lane timing
+        self._run_batches(len(starts), run)                   # shares beyond MAX_BATCH rows: `lanes` batches in flight
+        return [t for p_ in parts for t in p_]
 
     def generate_tokens_device(self, audio, lens_dev, lens: Sequence[int], max_tokens: Sequence[int], lang: str,
                                temperature=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2,

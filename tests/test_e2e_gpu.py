@@ -732,6 +732,31 @@ def test_run_sharded_over_rccl_world1(dev, small):
     assert got == want and got_resident == want
 
 
+def test_packed_share_larger_than_a_batch_is_pipelined_and_equal(dev, small):
+    """A rank's share beyond MAX_BATCH rows (dist.run_sharded hands it over as one device tensor): batches run two at a time on
+    their own lanes; tokens equal the sequential walk and the single-utterance calls, greedy and seeded sampling alike."""
+    from qwen3_asr_mlx_amd.audio import pack_audio
+    cfg, state, model = small
+    xs = [signal("speechlike", 30000 + 4000 * i, seed=300 + i) for i in range(5)]
+    budgets = [6, 9, 5, 8, 7]
+    packed, _, lens = pack_audio(xs, dev)
+    old_mb, old_lanes = model.MAX_BATCH, model.lanes
+    try:
+        model.MAX_BATCH = 2                                                   # 3 batches of the 5 rows
+        model.lanes = 2
+        piped = model.generate_tokens_packed(packed, lens, budgets, "English")
+        piped_s = model.generate_tokens_packed(packed, lens, budgets, "English", temperature=0.8, top_p=0.9, seed=11)
+        model.lanes = 1
+        serial = model.generate_tokens_packed(packed, lens, budgets, "English")
+        serial_s = model.generate_tokens_packed(packed, lens, budgets, "English", temperature=0.8, top_p=0.9, seed=11)
+    finally:
+        model.MAX_BATCH, model.lanes = old_mb, old_lanes
+    assert piped == serial and piped_s == serial_s
+    assert [len(t) for t in piped] == budgets
+    for i in range(len(xs)):
+        assert model.generate_tokens([xs[i]], [budgets[i]], "English")[0] == piped[i]
+
+
 def test_front_door_fails_fast_after_worker_death(dev, small, monkeypatch):
     """once the row worker has died, queued and later requests must fail instead of hanging."""
     import importlib
