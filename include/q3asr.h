@@ -63,7 +63,7 @@ int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int 
                     const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
                     void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream);
 /* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 64 = 64x64 tile, 128 = 128x128 tile, 8 = 256x256 8-phase LDS-DMA
- * pipeline where its preconditions hold).  All kernels give bit-identical results. */
+ * pipeline where its preconditions hold, 224 = the same pipeline on 224x256 tiles).  All kernels give bit-identical results. */
 int q3asr_gemm_force_kernel(int mode);
 /* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
 int q3asr_gemm_set_stamp(void* buf);

@@ -115,7 +115,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // (read as whole rows too) after it; arithmetic and rounding points are those of gemm_epilogue, so results are bit-identical.
 // Preconditions (checked on the host, else gemm_epilogue): N % 8 == 0, ldo / ldres multiples of 8, 16-byte aligned bases.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][8], int m_base, int n_base, int n0, int wn,
+template <int MI = 8>   // 16-row blocks per wave: 8 (128 rows) or 7 (the 224-row tile's 112)
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n_base, int n0, int wn,
                                                   char* st, int lane) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // lane-derived addresses are recomputed here from an opaque copy of the lane id: hoisted above the K loop they would
@@ -126,7 +127,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         const int n_out0 = (n0 >> 1) + wn * 32;
         const int rr = lane >> 2, rc = lane & 3;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < MI; ++i) {
             char* blk = st + (i & 1) * 2048;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
@@ -154,7 +155,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         const int rc = lane & 7;
         const int n = n_base + 8 * rc;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < MI; ++i) {
             char* blk = st + (i & 1) * 2048;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -197,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     const int rc = lane & 15;
     const int n = n_base + 4 * rc;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 v = acc[j][i];
@@ -568,7 +569,7 @@ struct G8Ctx {
 __device__ __attribute__((aligned(16))) unsigned g8_zero[4];               // source of padding taps and of k >= K
 
 // DMA of half-tile S[s]: kind = s & 3 (0 B0, 1 A0, 2 B1, 3 A1), K tile = s >> 2 (clamped: the ring keeps turning past the end)
-template <int KIND, int SLOT, int CONV>
+template <int KIND, int SLOT, int CONV, int WR = 128>   // WR: rows of the output tile per wave row (128; 112 in the 224-row tile)
 __device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile, int tm0, int tn0) {
     const int kt = min(ktile, c.nk - 1);
     constexpr int h = KIND >> 1;
@@ -578,7 +579,7 @@ __device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile, int tm0, int
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const char* src;
-            if constexpr (KIND & 1) src = c.A + ((unsigned)min(tm0 + q * 128 + h * 64 + c.rr, c.M - 1) * c.lda2 + kb);
+            if constexpr (KIND & 1) src = c.A + ((unsigned)min(tm0 + q * WR + h * 64 + c.rr, c.M - 1) * c.lda2 + kb);
             else src = c.W + ((unsigned)min(tn0 + q * 128 + h * 32 + c.rw, c.N - 1) * c.ldw2 + kb);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + 8192 * q), 16, 0, 0);
@@ -612,11 +613,11 @@ __device__ __forceinline__ void g8_issue(const G8Ctx& c, int ktile, int tm0, int
     }
 }
 
-template <int SLOT>
+template <int SLOT, int NI = 4>
 __device__ __forceinline__ void g8_read_a(const G8Ctx& c, bf16x8 (&af)[4][2]) {
     const char* b = c.ring + SLOT * G8_SLOT;
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
+    for (int ii = 0; ii < NI; ++ii) {
         af[ii][0] = *reinterpret_cast<const bf16x8*>(b + (c.rdA + ii * 2048));
         af[ii][1] = *reinterpret_cast<const bf16x8*>(b + ((c.rdA + ii * 2048) ^ 64u));
     }
@@ -630,12 +631,12 @@ __device__ __forceinline__ void g8_read_b(const G8Ctx& c, bf16x8 (&bf)[2][2]) {
         bf[jj][1] = *reinterpret_cast<const bf16x8*>(b + ((c.rdB + jj * 2048) ^ 64u));
     }
 }
-template <int MH, int NH, bool F8 = false>
-__device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][8], const bf16x8 (&af)[4][2], const bf16x8 (&bf)[2][2]) {
+template <int MH, int NH, bool F8 = false, int MI1 = 4>   // MI1: 16-row tiles in the second M half of a wave (4, or 3: 224-row tile)
+__device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][4 + MI1], const bf16x8 (&af)[4][2], const bf16x8 (&bf)[2][2]) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
+        for (int ii = 0; ii < (MH ? MI1 : 4); ++ii)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 if constexpr (F8) {
@@ -656,23 +657,24 @@ __device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][8], const bf16x8 (&af)[4
 
 // One phase.  PH = g & 7; `tile` = K tile whose half-tile S[g+7] is issued ((g + 7) >> 2).
 // b0cur: B0 fragments of the K tile being computed; b0nxt: filled in phase 3 (mod 4) for the next K tile.
-template <int PH, int CONV>
-__device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0, int tn0, f32x4 (&acc)[4][8], bf16x8 (&af)[4][2],
+template <int PH, int CONV, int MI1 = 4>
+__device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0, int tn0, f32x4 (&acc)[4][4 + MI1], bf16x8 (&af)[4][2],
                                          bf16x8 (&b1)[2][2], bf16x8 (&b0cur)[2][2], bf16x8 (&b0nxt)[2][2]) {
     constexpr int RS = (PH + 1) & 7, RK = (PH + 1) & 3;          // slot / kind read in this phase
-    if constexpr (RK == 1 || RK == 3) g8_read_a<RS>(c, af);
+    if constexpr (RK == 1) g8_read_a<RS>(c, af);
+    else if constexpr (RK == 3) g8_read_a<RS, MI1>(c, af);
     else if constexpr (RK == 2) g8_read_b<RS>(c, b1);
     else g8_read_b<RS>(c, b0nxt);
-    g8_issue<(PH + 7) & 3, (PH + 7) & 7, CONV>(c, issue_tile, tm0, tn0);
+    g8_issue<(PH + 7) & 3, (PH + 7) & 7, CONV, 16 * (4 + MI1)>(c, issue_tile, tm0, tn0);
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    if constexpr ((PH & 3) == 0) g8_mfma<0, 0, CONV == 2>(acc, af, b0cur);
-    else if constexpr ((PH & 3) == 1) g8_mfma<0, 1, CONV == 2>(acc, af, b1);
-    else if constexpr ((PH & 3) == 2) g8_mfma<1, 1, CONV == 2>(acc, af, b1);
-    else g8_mfma<1, 0, CONV == 2>(acc, af, b0cur);
+    if constexpr ((PH & 3) == 0) g8_mfma<0, 0, CONV == 2, MI1>(acc, af, b0cur);
+    else if constexpr ((PH & 3) == 1) g8_mfma<0, 1, CONV == 2, MI1>(acc, af, b1);
+    else if constexpr ((PH & 3) == 2) g8_mfma<1, 1, CONV == 2, MI1>(acc, af, b1);
+    else g8_mfma<1, 0, CONV == 2, MI1>(acc, af, b0cur);
     __builtin_amdgcn_s_setprio(0);
     G8_BAR();
 }
@@ -681,18 +683,24 @@ __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0
 // keeps turning across the seam, so the first seven half-tiles of the next output tile are already in flight while the
 // last phases of the current one compute and while the epilogue stores; the wave rows re-align for the epilogue and
 // stagger again after it.  The conv variant takes one tile per workgroup (its per-row im2col state is per tile).
-template <int CONV>      // 0: plain bf16, 1: implicit-GEMM conv (bf16), 2: plain fp8 (e4m3 x e4m3, scales in the epilogue)
+// MI1 = 3 (plain GEMMs only): a 224-row tile, 112 rows per wave row = a full 64-row first half and a 48-row second half (three
+// of its four MFMA tiles; the half-tile images keep their 128-row slots, the unused 16 rows per wave row are staged and ignored).
+// Round 3: M = 12,480 / 13,056 rows make 196 / 408 / 784 / 816 tiles of 256 rows on 256 CUs -- rounds that are 77-80 % full --
+// and 224 / 472 / 896 / 944 tiles of 224: the same number of rounds, each 0.875 of the work (gemm_launch picks per shape).
+template <int CONV, int MI1 = 4>      // CONV 0: plain bf16, 1: implicit-GEMM conv (bf16), 2: plain fp8 (e4m3 x e4m3, scales in the epilogue)
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int total_tiles) {
+    constexpr int MI = 4 + MI1, WR = 16 * MI, TM = 2 * WR;                 // MFMA row tiles per wave, rows per wave row, rows per tile
+    static_assert(MI1 == 4 || (MI1 == 3 && CONV != 1), "the conv variant keeps 256-row tiles");
     extern __shared__ __attribute__((aligned(16))) char smem8[];          // the only LDS object: 8 ring slots x 16 KiB + 8 x 4 KiB epilogue staging
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = (p.N + G2_T - 1) / G2_T, tiles_m = (p.M + G2_T - 1) / G2_T;
+    const int tiles_n = (p.N + G2_T - 1) / G2_T, tiles_m = (p.M + TM - 1) / TM;
     const int group = GROUP_M * tiles_n;
     auto tile_origin = [&](int v, int& m0, int& n0) {                       // same grouped, XCD-aware order as the other kernels
         const unsigned t = xcd_remap((unsigned)v, (unsigned)total_tiles);
         const int first_m = (t / group) * GROUP_M;
         const int gm = min(tiles_m - first_m, GROUP_M);
-        m0 = (first_m + (int)(t % group) % gm) * G2_T;
+        m0 = (first_m + (int)(t % group) % gm) * TM;
         n0 = ((int)(t % group) / gm) * G2_T;
     };
     int v = blockIdx.x, m0, n0, m0n, n0n;
@@ -745,16 +753,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
     c.rdA = (unsigned)((wr * 64 + li) * 128 + ((g ^ (li >> 1)) << 4));
     c.rdB = (unsigned)((wc * 32 + li) * 128 + ((g ^ (li >> 1)) << 4));
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][MI];
     bf16x8 af[4][2], b1[2][2], b0e[2][2], b0o[2][2];
     int n_stamp = 0;
 #define G8_STAMP() do { if (p.stamp && blockIdx.x == 0 && tid == 0 && n_stamp < 16) p.stamp[n_stamp++] = wall_clock64(); } while (0)
     G8_STAMP();                                                             // 0: entry (after the address setup)
 
     // ---- prologue: S[0..6] in flight, S[0] (B0 of tile 0) and S[1] landed before the first reads
-    g8_issue<0, 0, CONV>(c, 0, m0, n0); g8_issue<1, 1, CONV>(c, 0, m0, n0); g8_issue<2, 2, CONV>(c, 0, m0, n0);
-    g8_issue<3, 3, CONV>(c, 0, m0, n0); g8_issue<0, 4, CONV>(c, 1, m0, n0); g8_issue<1, 5, CONV>(c, 1, m0, n0);
-    g8_issue<2, 6, CONV>(c, 1, m0, n0);
+    g8_issue<0, 0, CONV, WR>(c, 0, m0, n0); g8_issue<1, 1, CONV, WR>(c, 0, m0, n0); g8_issue<2, 2, CONV, WR>(c, 0, m0, n0);
+    g8_issue<3, 3, CONV, WR>(c, 0, m0, n0); g8_issue<0, 4, CONV, WR>(c, 1, m0, n0); g8_issue<1, 5, CONV, WR>(c, 1, m0, n0);
+    g8_issue<2, 6, CONV, WR>(c, 1, m0, n0);
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     G8_BAR();
     g8_read_b<0>(c, b0e);
@@ -766,21 +774,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (wr == 1) G8_BAR();                                             // the second wave row runs one barrier behind
         for (int it = 0; it < iters; ++it) {
             const int t2 = 2 * it;
             const bool seam = CONV != 1 && it == last_it;                  // uniform: issues beyond this tile's K belong to the next tile
             const int im0 = seam ? m0n : m0, in0 = seam ? n0n : n0;
             const int wrap = seam ? c.nk : 0;
-            g8_phase<0, CONV>(c, t2 + 1, m0, n0, acc, af, b1, b0e, b0o);            // S[8it+7]  = A1 of tile 2it+1
-            g8_phase<1, CONV>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // S[8it+8]  = B0 of tile 2it+2
-            g8_phase<2, CONV>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);
-            g8_phase<3, CONV>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // reads B0 of tile 2it+1 into b0o
-            g8_phase<4, CONV>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // S[8it+11] = A1 of tile 2it+2
-            g8_phase<5, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
-            g8_phase<6, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
-            g8_phase<7, CONV>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
+            g8_phase<0, CONV, MI1>(c, t2 + 1, m0, n0, acc, af, b1, b0e, b0o);            // S[8it+7]  = A1 of tile 2it+1
+            g8_phase<1, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // S[8it+8]  = B0 of tile 2it+2
+            g8_phase<2, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);
+            g8_phase<3, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // reads B0 of tile 2it+1 into b0o
+            g8_phase<4, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // S[8it+11] = A1 of tile 2it+2
+            g8_phase<5, CONV, MI1>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
+            g8_phase<6, CONV, MI1>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
+            g8_phase<7, CONV, MI1>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
         }
         if (wr == 0) G8_BAR();                                             // re-align the wave rows
         G8_STAMP();                                                         // 2 + 2t: K loop of tile t done
@@ -793,14 +801,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
                 const int nb = min(n0 + wc * 64 + j * 16 + 4 * g2, p.N - 4);
                 const f32x4 sw = *reinterpret_cast<const f32x4*>(p.w_scale + nb);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float sa = p.a_scale[min(m0 + wr * 128 + i * 16 + li2, p.M - 1)];
+                for (int i = 0; i < MI; ++i) {
+                    const float sa = p.a_scale[min(m0 + wr * WR + i * 16 + li2, p.M - 1)];
                     acc[j][i] *= sw * sa;
                 }
             }
         }
-        if (p.lds_epi) gemm_epilogue_lds(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
-        else gemm_epilogue<8>(p, acc, m0 + wr * 128, n0 + wc * 64, n0, wc, g, li);
+        if (p.lds_epi) gemm_epilogue_lds<MI>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
+        else gemm_epilogue<MI>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, g, li);
         G8_STAMP();                                                         // 3 + 2t: epilogue of tile t issued
         v += gridDim.x;
         if (CONV == 1 || v >= total_tiles) break;                          // uniform
@@ -819,7 +827,7 @@ static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_s
 extern "C" int q3asr_gemm_set_stamp(void* buf) { g_gemm_stamp = (unsigned long long*)buf; return 0; }
 
 extern "C" int q3asr_gemm_force_kernel(int mode) {
-    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 8 || mode == 64, "gemm_force_kernel: mode %d (0 auto, 64, 128, 8 = 8-phase)", mode);
+    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 8 || mode == 64 || mode == 224, "gemm_force_kernel: mode %d (0 auto, 64, 128, 8 = 8-phase with 256-row tiles, 224 = 8-phase with 224-row tiles)", mode);
     g_gemm_mode = mode;
     return 0;
 }
@@ -828,7 +836,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
     const unsigned tiles = (unsigned)((p.M + BM - 1) / BM) * (unsigned)((p.N + BN - 1) / BN);
     const bool fast = !conv && p.K % BK == 0 && (long)p.M * p.lda < (1L << 31) && (long)p.N * p.ldw < (1L << 31);
     const unsigned tiles256 = (unsigned)((p.M + G2_T - 1) / G2_T) * (unsigned)((p.N + G2_T - 1) / G2_T);
-    const int mode = force_mode ? force_mode : g_gemm_mode;  // 0 auto; 128 / 8 pin a kernel (A/B runs, tests)
+    const int mode = force_mode ? force_mode : g_gemm_mode;  // 0 auto; 64 / 128 / 8 / 224 pin a kernel (A/B runs, tests)
     // Kernel choice (measured on the prefill / encoder shapes, tools/bench_gemm.py): the 8-phase kernel wins wherever its
     // preconditions hold and the grid fills the chip: one 256^2 tile costs ~2.6 128^2 tiles, one workgroup per CU against
     // two (fc1 with its erf-GELU epilogue: 156 us against 181 us).
@@ -839,7 +847,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
     const bool can8c = conv && p.K >= 256 && (long)p.N * p.ldw < (1L << 31) &&
                        (256L / (p.Hout * p.Wout) + 3) * p.Hin * p.Win * p.Cin * 2 < (1L << 31);
     const bool want8c = can8c && tiles256 >= 192;
-    if ((mode == 8 && (can8 || can8c)) || (mode == 0 && (want8 || want8c))) {      // deep-pipelined 8-phase kernel
+    if (((mode == 8 || mode == 224) && (can8 || can8c)) || (mode == 0 && (want8 || want8c))) {      // deep-pipelined 8-phase kernel
         // Tried (round 3, commit 'Experiment: 256x128 half-tile GEMM ...', profiles/r03_gemm2w_experiment.txt): 256 x 128 tiles, 4 waves and
         // an 80 KiB ring so that TWO workgroups share a CU (one's epilogue and pipeline fill under the other's K loop, half-size
         // scheduling units): bit-identical and race-screened, but no faster -- fc1 144.9 vs 143.7 us, encoder qkv 85.9 vs 82.3,
@@ -859,6 +867,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
         if (!attr8) {
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
             attr8 = true;
         }
         if (conv) hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), G8_LDS, s, p8, (int)tiles256);
@@ -868,8 +877,14 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
             // drain before the next tile's counted waits can pass (measured: +8 % at K <= 2048, -2..3 % on long-K or
             // SwiGLU tiles, tools/bench_gemm.py)
             const bool persist = p.K <= 2048 && p.act != 2;
-            const unsigned grid = persist && tiles256 > 256u ? 256u : tiles256;
-            hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles256);
+            // Tile height: a workgroup owns a CU, so a launch costs rounds x tile height; 224-row tiles where that is less
+            // (M = 12,480: 196 tiles of 256 rows or 224 of 224 for N = 1,024 -- one round either way, the second 1/8 shorter).
+            const unsigned tiles224 = (unsigned)((p.M + 223) / 224) * (unsigned)((p.N + G2_T - 1) / G2_T);
+            const bool t224 = mode == 224 || (mode == 0 && ((tiles224 + 255) / 256) * 224u < ((tiles256 + 255) / 256) * 256u);
+            const unsigned tiles8 = t224 ? tiles224 : tiles256;
+            const unsigned grid = persist && tiles8 > 256u ? 256u : tiles8;
+            if (t224) hipLaunchKernelGGL((gemm8p_kernel<0, 3>), dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles8);
+            else hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles8);
         }
         return;
     }
@@ -972,8 +987,17 @@ extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale,
     p.lds_epi = 1;
     const unsigned tiles256 = (unsigned)((M + G2_T - 1) / G2_T) * (unsigned)((N + G2_T - 1) / G2_T);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS); attr = true; }
-    const bool persist = act != 2 && tiles256 > 256u;
-    hipLaunchKernelGGL(gemm8p_kernel<2>, dim3(persist ? 256u : tiles256), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles256);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+        attr = true;
+    }
+    // tile height as in gemm_launch: rounds x height, 224-row tiles where that is less (q3asr_gemm_force_kernel 8 / 224 pin one)
+    const unsigned tiles224 = (unsigned)((M + 223) / 224) * (unsigned)((N + G2_T - 1) / G2_T);
+    const bool t224 = g_gemm_mode == 224 || (g_gemm_mode != 8 && ((tiles224 + 255) / 256) * 224u < ((tiles256 + 255) / 256) * 256u);
+    const unsigned tiles8 = t224 ? tiles224 : tiles256;
+    const bool persist = act != 2 && tiles8 > 256u;
+    if (t224) hipLaunchKernelGGL((gemm8p_kernel<2, 3>), dim3(persist ? 256u : tiles8), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles8);
+    else hipLaunchKernelGGL(gemm8p_kernel<2>, dim3(persist ? 256u : tiles8), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles8);
     return q3_check_launch("gemm_fp8");
 }

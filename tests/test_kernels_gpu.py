@@ -191,10 +191,11 @@ def test_gemm_swiglu(dev):
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 512, 384), (1000, 768, 1024), (2050, 1280, 2048), (515, 256, 6144),
                                    (777, 992, 512),               # ragged N as well (last tile column 224 wide)
                                    (4396, 4096, 1024),            # 288 tiles: the 8-phase kernel walks two tiles per workgroup
+                                   (12480, 1024, 1024),           # the encoder's out projection: 196 tiles of 256 rows, 224 of 224
                                    (70, 128, 64), (130, 192, 192)])   # fewer K tiles than the 64^2 kernel keeps in flight (8-phase n/a: 128^2 twice)
 def test_gemm_kernels_agree_bitwise(dev, M, N, K):
-    """The 64x64, the 128x128 and the 256x256 8-phase LDS-DMA kernel accumulate every output in the same order (k ascending, one
-    MFMA chain): bit-identical results, plain, fp32-out and through the epilogues (bias+GELU, bf16 residual, SwiGLU),
+    """The 64x64, the 128x128 and the 8-phase LDS-DMA kernel (256x256 and 224x256 tiles) accumulate every output in the same order
+    (k ascending, one MFMA chain): bit-identical results, plain, fp32-out and through the epilogues (bias+GELU, bf16 residual, SwiGLU),
     including ragged M edges -- which is what makes a clip's result independent of the batch it is decoded in."""
     from qwen3_asr_mlx_amd import _lib, ops
     A = rnd((M, K), dev, 40, 1.0)
@@ -210,7 +211,7 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     rm = rm.to(dev)
     outs = {}
     try:
-        for mode in (128, 8, 64):
+        for mode in (128, 8, 64, 224):
             _lib.call("q3asr_gemm_force_kernel", mode)
             o32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
             ops.gemm(A, W, M, N, K, o32, out_fp32=True)
@@ -228,7 +229,7 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     finally:
         _lib.call("q3asr_gemm_force_kernel", 0)
     torch.testing.assert_close(outs[8][0].cpu(), _gemm_ref(A, W), atol=2e-3, rtol=1e-3)
-    for mode in (8, 64):
+    for mode in (8, 64, 224):
         for a, b in zip(outs[128], outs[mode]):
             assert torch.equal(a, b), mode
 
@@ -258,11 +259,11 @@ def test_gemm_8phase_direct_epilogue_fallback(dev):
         assert torch.equal(a, b)
 
 
-def test_gemm_8phase_is_stable_under_load(dev):
+@pytest.mark.parametrize("mode", [8, 224])
+def test_gemm_8phase_is_stable_under_load(dev, mode):
     """Race screen for the 8-phase pipeline (LDS-DMA data is ordered only by counted waits + barriers): 30 back-to-back
-    launches of a chip-filling shape, each compared bit for bit with the 128x128 kernel's result."""
+    launches of a chip-filling shape, each compared bit for bit with the 128x128 kernel's result; both tile heights."""
     from qwen3_asr_mlx_amd import _lib, ops
-    mode = 8
     M, N, K = 4096, 4096 + 256, 2048 + 128
     A = rnd((M, K), dev, 50, 1.0)
     W = rnd((N, K), dev, 51, 1.0 / math.sqrt(K))
@@ -315,6 +316,21 @@ def test_gemm_fp8_on_the_fp8_mfma(dev, M, N, K):
     r3 = bfr(ref.float()).reshape(M, I // 16, 2, 16)
     g, u = r3[:, :, 0].reshape(M, I), r3[:, :, 1].reshape(M, I)
     torch.testing.assert_close(osw.float().cpu(), bfr(g * torch.sigmoid(g) * u), atol=2e-2, rtol=2e-2)
+    # both tile heights of the 8-phase kernel give the same bits (one k-ascending chain per output)
+    from qwen3_asr_mlx_amd import _lib
+    by_tile = {}
+    try:
+        for mode in (8, 224):
+            _lib.call("q3asr_gemm_force_kernel", mode)
+            o_a, o_b, o_c = torch.empty_like(out), torch.empty_like(out), torch.empty_like(osw)
+            ops.gemm_fp8(a8, sa, q8, sw, M, N, K, o_a)
+            ops.gemm_fp8(a8, sa, q8, sw, M, N, K, o_b, res=hb)
+            ops.gemm_fp8(a8, sa, q8, sw, M, N, K, o_c, act=2)
+            by_tile[mode] = (o_a, o_b, o_c)
+    finally:
+        _lib.call("q3asr_gemm_force_kernel", 0)
+    for x8, x224, auto in zip(by_tile[8], by_tile[224], (out, out2, osw)):
+        assert torch.equal(x8, x224) and torch.equal(x8, auto)
     # RMSNorm fused quantiser == rmsnorm_bf16 followed by the plain quantiser
     if K in (1024, 2048):
         wn = rnd((K,), dev, 73) + 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time q3asr_gemm_bf16 on the prefill / encoder shapes of the headline workload (random operands), kernels interleaved in
-one process.  Usage: python tools/bench_gemm.py [rounds] [modes=0]  (modes: comma list of 0 auto, 128, 256, 8, 2)."""
+one process.  Usage: python tools/bench_gemm.py [rounds] [modes=0]  (modes: comma list of 0 auto, 64, 128, 8 = 8-phase 256-row tiles, 224 = 8-phase 224-row tiles)."""
 import sys
 from pathlib import Path
 import torch
