@@ -9,6 +9,7 @@
 // These are exactly the A / B operand fragments of v_mfma_f32_16x16x32_bf16, so the GEMM is
 // global_load_dwordx4 -> MFMA with no LDS and no barrier; X16 (128 KB at K = 2048) stays in L1/L2.
 #include "common.h"
+#include <atomic>
 
 __device__ __forceinline__ long x16_index(int m, int k, int MT) {      // element offset of X[m][k]
     return ((long)(k >> 5) * MT + (m >> 4)) * 512 + ((((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
@@ -319,7 +320,7 @@ static int skinny3_launch(const char* who, const void* X16, const FuseNorm* fuse
 #define Q3_R(MT_, EPI_) do { if (RT == 1) Q3_F(MT_, EPI_, 1); else if (RT == 2) Q3_F(MT_, EPI_, 2); else Q3_F(MT_, EPI_, 4); } while (0)
 #define Q3_M(EPI_) do { if (MT == 1) Q3_R(1, EPI_); else if (MT == 2) Q3_R(2, EPI_); else Q3_R(4, EPI_); } while (0)
 #define Q3_LZ(EPI_, RT_, F8_) do {                                                                                                   \
-        static bool attr = false;                                                                                                    \
+        static std::atomic<bool> attr{false};                                                                                                    \
         if (!attr) { (void)hipFuncSetAttribute((const void*)skinny3_kernel<1, EPI_, RT_, F8_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr = true; } \
         hipLaunchKernelGGL((skinny3_kernel<1, EPI_, RT_, F8_, true>), grid, blk, lds, s, x, W16, M, N, K, kslice, wg_ksplit, w_scale, slab, o, (long)ldo, fz); \
     } while (0)
@@ -505,10 +506,10 @@ static void skinny4_go(dim3 grid, hipStream_t s, const void* X16, const FuseNorm
     constexpr size_t image = (size_t)WAVES * TPW * MT * 64 * sizeof(f32x4);
     static_assert(image <= 160 * 1024, "skinny4: partial-sum image exceeds LDS");
     const size_t lds = image + (FUSE ? (size_t)K * 8 : 0);   // + two bf16 rows and K floats
-    static size_t granted = 64 * 1024;
-    if (lds > granted) {
+    static std::atomic<size_t> granted{64 * 1024};   // host threads of several lanes launch concurrently: the attribute call is idempotent,
+    if (lds > granted.load(std::memory_order_relaxed)) {                                      // the flag only saves repeating it
         (void)hipFuncSetAttribute((const void*)skinny4_kernel<MT, TPW, NKS, EPI, WAVES, F8, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        granted = lds;
+        granted.store(lds, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((skinny4_kernel<MT, TPW, NKS, EPI, WAVES, F8, FUSE>), grid, dim3(64 * WAVES), lds, s, (const bf16*)X16, W, M, N, K, w_scale,
                        slab, (bf16*)out, ldo, fz);
@@ -1099,7 +1100,7 @@ extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_
     float* part = (float*)workspace;
     int* counters = (int*)(part + (int64_t)B * nkv * nc * ADF_PART);
     const int G = adf_chunks_per_wg(B * nkv, nc);
-    static bool attr = false;
+    static std::atomic<bool> attr{false};
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
         (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);

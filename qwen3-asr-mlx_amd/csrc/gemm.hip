@@ -15,6 +15,7 @@
 // SwiGLU pair (gate, up) of a feature sits in the same lane and register.
 // Bound: MFMA (dense bf16 peak 2.5 PFLOP/s); algorithmic flops = 2*M*N*K.
 #include "common.h"
+#include <atomic>
 #include <stdlib.h>
 
 #define BM 128
@@ -863,7 +864,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
         p8.lds_epi = p.N % 8 == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0 && (p.ldo * esz) % 16 == 0 &&
                      (p.res_kind == 0 || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
                      (!p.bias || ((uintptr_t)p.bias & 15) == 0);
-        static bool attr8 = false;
+        static std::atomic<bool> attr8{false};
         if (!attr8) {
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
@@ -986,7 +987,7 @@ extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale,
                "gemm_fp8: out / w_scale / res must be 16-byte aligned");
     p.lds_epi = 1;
     const unsigned tiles256 = (unsigned)((M + G2_T - 1) / G2_T) * (unsigned)((N + G2_T - 1) / G2_T);
-    static bool attr = false;
+    static std::atomic<bool> attr{false};
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
         (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);

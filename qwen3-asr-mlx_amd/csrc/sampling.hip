@@ -24,6 +24,7 @@
 //       distributional parity only).
 //   bookkeeping         append to out_tokens unless finished, EOS / budget -> finished, advance pos.
 #include "common.h"
+#include <atomic>
 
 #define SMP_THREADS 1024
 #define SMP_WAVES (SMP_THREADS / 64)
@@ -580,7 +581,7 @@ extern "C" int q3asr_sample_step(const void* logits, int64_t ld, int B, int V, i
         hipLaunchKernelGGL(sample_greedy_kernel, dim3(B), dim3(SMP_THREADS), bitmap, (hipStream_t)stream, p);
     } else {
         const size_t lds = SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4 + bitmap; // up to 112 KiB: needs the opt-in (once per process)
-        static bool attr_set = false;
+        static std::atomic<bool> attr_set{false};
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)sample_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4 + 64 * SMP_THREADS);
