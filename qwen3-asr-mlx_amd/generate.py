@@ -137,9 +137,9 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
                 while done < steps:
                     # several steps per launch while that cannot overshoot the budget
                     done += decoder.replay_step(ws, multi=steps - done >= decoder.MULTI_STEPS)
-                    if done - checked >= 16:
+                    if done - checked >= FINISH_CHECK_EVERY:
                         checked = done
-                        if bool(ws.finished.all()):
+                        if _all_finished(ws):
                             break
             torch.cuda.current_stream().wait_stream(side)
         else:
@@ -154,6 +154,16 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
     toks = ws.out_tokens.cpu()
     out = [toks[b, : n_gen[b]].tolist() for b in range(B)]
     return (out, ws, cache) if return_state else out
+
+
+# Decode steps between two looks at the `finished` flags (a device-to-host synchronisation each).  Measured (tools/ab_decode_loop.py,
+# profiles/r03_decode_loop_cadence.txt): the longer the stream runs without a host synchronisation the slower its steps get --
+# a batch-32 request takes 245.7 ms with a look after every 4-step replay, 246.1 at 8, 247.4 at 16, 250.0 at 32, 255.5 at 64 and
+# 259.7 with none, one 16-step graph per look the same as four 4-step ones; batch 1: 154.0 / 155.0 / 156.6 ms at 4 / 16 / 32.
+FINISH_CHECK_EVERY = 4
+def _all_finished(ws) -> bool:
+    """One look at the rows' `finished` flags: a reduction on the current stream and a synchronising read."""
+    return bool(ws.finished.all())
 
 
 ROW_FAILED = 2                # include/q3asr.h Q3ASR_ROW_FAILED: the device-side error flag in `finished`

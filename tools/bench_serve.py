@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Open-loop load on the queue front door (serve.ContinuousTranscriber) at the 1.7B shapes: 30 s clips, 128 tokens each,
 Poisson arrivals at several rates; per-request latency (submit -> result) and sustained throughput.
-Usage: bench_serve.py [rows] [rate,rate,...] [seconds] [async] [min_admit]"""
+Usage: bench_serve.py [rows] [rate,rate,...] [seconds] [async|sync] [min_admit|-] [check_every]"""
 import json
 import sys
 import threading
@@ -19,7 +19,8 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 rates = [float(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [10, 25, 50, 80, 110]
 seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 6.0
 async_admit = len(sys.argv) > 4 and sys.argv[4] == "async"
-min_admit = int(sys.argv[5]) if len(sys.argv) > 5 else None
+min_admit = int(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+check_every = int(sys.argv[6]) if len(sys.argv) > 6 else None
 dev = torch.device("cuda:0")
 cfg = ModelConfig()
 state = synth.random_state(cfg, seed=0, device=dev)
@@ -30,8 +31,9 @@ NTOK = 128
 t0 = time.perf_counter()
 one = [model.transcribe(clips[0], max_tokens=NTOK) for _ in range(4)]
 t_one = (time.perf_counter() - t0) / 4
-out = {"async_admit": async_admit, "min_admit": min_admit, "rows": rows, "clip_seconds": 30, "tokens": NTOK, "transcribe_one_at_a_time_ms": round(1e3 * t_one, 1), "runs": []}
-srv = q.ContinuousTranscriber(model, rows=rows, chunk_duration=60.0, max_new_tokens=NTOK, async_admit=async_admit, min_admit=min_admit)
+out = {"async_admit": async_admit, "min_admit": min_admit, "check_every": check_every, "rows": rows, "clip_seconds": 30, "tokens": NTOK, "transcribe_one_at_a_time_ms": round(1e3 * t_one, 1), "runs": []}
+kw = {} if check_every is None else {"check_every": check_every}
+srv = q.ContinuousTranscriber(model, rows=rows, chunk_duration=60.0, max_new_tokens=NTOK, async_admit=async_admit, min_admit=min_admit, **kw)
 for f in [srv.submit(clips[i % 16], max_tokens=NTOK) for i in range(rows)]:        # warm-up: plans, graph
     f.result()
 for rate in rates:
