@@ -27,10 +27,11 @@ arms = [(int(a_[0]), int(a_[1]), a_[2] if len(a_) > 2 else "look", len(a_) > 3 a
 # fourth field "pp": two instantiations of the long graph, replayed alternately (is a replay of an executable graph that is still
 # in flight what costs?)
 # what a "look" does (third field): look = reduction + synchronising read (the product); sync = stream synchronise only;
-# kernel = the reduction kernel without waiting for it; none = nothing
+# kernel = the reduction kernel without waiting for it; query = hipStreamQuery (non-blocking); none = nothing
 looks = {"look": gen._all_finished,
          "sync": lambda ws: (torch.cuda.current_stream().synchronize(), False)[1],
          "kernel": lambda ws: (ws.finished.all(), False)[1],
+         "query": lambda ws: (torch.cuda.current_stream().query(), False)[1],      # non-blocking: lets the runtime retire what has finished
          "none": lambda ws: False}
 res, toks = {k: [] for k in arms}, {}
 dec = model._decoder
