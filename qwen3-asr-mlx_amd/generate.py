@@ -141,6 +141,10 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
                         checked = done
                         if _all_finished(ws):
                             break
+            # The host waits here, BEFORE the caller's stream is told to wait for the side stream: a hardware queue that sits
+            # blocked on another queue's signal slows every kernel of the running queue (~0.5 us each, 110 us per decode step:
+            # tools/ab_decode_loop.py), and the token read below synchronises anyway.
+            side.synchronize()
             torch.cuda.current_stream().wait_stream(side)
         else:
             while done < steps:
@@ -156,11 +160,11 @@ def generate_batch(decoder: TextDecoder, enc_feats, tok_counts: Sequence[int], p
     return (out, ws, cache) if return_state else out
 
 
-# Decode steps between two looks at the `finished` flags (a device-to-host synchronisation each).  Measured (tools/ab_decode_loop.py,
-# profiles/r03_decode_loop_cadence.txt): the longer the stream runs without a host synchronisation the slower its steps get --
-# a batch-32 request takes 245.7 ms with a look after every 4-step replay, 246.1 at 8, 247.4 at 16, 250.0 at 32, 255.5 at 64 and
-# 259.7 with none, one 16-step graph per look the same as four 4-step ones; batch 1: 154.0 / 155.0 / 156.6 ms at 4 / 16 / 32.
-FINISH_CHECK_EVERY = 4
+# Decode steps between two looks at the `finished` flags (a device-to-host synchronisation each: ~45 us of idle GPU).  Round 3
+# (tools/ab_decode_loop.py, profiles/r03_decode_loop_cadence.txt): with the caller's stream no longer parked on the decode stream
+# while the loop runs (generate_batch below) a batch-32 request takes 244.9 / 244.4 / 243.8 / 243.6 ms at a look every 4 / 16 / 32 /
+# 64 steps; 16 keeps the wait for the last row's EOS short.
+FINISH_CHECK_EVERY = 16
 def _all_finished(ws) -> bool:
     """One look at the rows' `finished` flags: a reduction on the current stream and a synchronising read."""
     return bool(ws.finished.all())

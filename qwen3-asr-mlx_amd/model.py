@@ -403,16 +403,25 @@ class Qwen3ASR:
         """Same, with the padded fp32 audio [B][Lmax] and int32 lengths already resident in HBM."""
         if self._encoder is None or self._decoder is None:
             raise TypeError("'NoneType' object is not callable")
-        dev = self._decoder.device
-        fe = get_frontend(dev)
-        mel, n_frames = fe(audio, lens_dev, lens)
-        feats, tok_counts = self._encoder.forward_batch(mel, n_frames)
-        lang_ids = self._tokenizer.encode(f" {lang}")
+        import torch
+        from .generate import _side_stream
         from .tokenizer import build_prompt
-        prompts = [build_prompt(n, lang_ids) for n in tok_counts]
-        return generate_batch(self._decoder, feats, tok_counts, prompts, list(max_tokens), temperature, top_p, top_k,
-                              repetition_penalty, repetition_context_size,
-                              seed=seed if seed is not None else (_next_seed() if temperature else 0), use_graph=self.use_graph)
+        dev = self._decoder.device
+        # The whole request runs on ONE stream, the lane's decode stream (graph capture needs a non-legacy stream anyway): a
+        # stream that sits waiting for another one mid-request -- the decode stream for the prefill, the caller's stream for the
+        # decode loop -- is a hardware queue blocked on a signal, and that slows every kernel of the queue that is running by
+        # ~0.5 us (measured on the decode loop, tools/ab_decode_loop.py).  The only wait is here, for the caller's audio.
+        side = _side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fe = get_frontend(dev)
+            mel, n_frames = fe(audio, lens_dev, lens)
+            feats, tok_counts = self._encoder.forward_batch(mel, n_frames)
+            lang_ids = self._tokenizer.encode(f" {lang}")
+            prompts = [build_prompt(n, lang_ids) for n in tok_counts]
+            return generate_batch(self._decoder, feats, tok_counts, prompts, list(max_tokens), temperature, top_p, top_k,
+                                  repetition_penalty, repetition_context_size,
+                                  seed=seed if seed is not None else (_next_seed() if temperature else 0), use_graph=self.use_graph)
 
     def _resolve_language(self, language: Optional[str]) -> str:
         if language is None or language.lower() in ("auto", ""):
