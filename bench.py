@@ -446,14 +446,22 @@ def main() -> None:
             dec_.sample_step(ws, ws.logits, sampling)
         _, t_pre = timed(prefill)
 
-        def decode():
+        def decode():                                     # the product's loop (generate.generate_batch): one eager step, then replays of
+            import importlib                              # the captured 4-step graph with a look at the finished flags every 16 steps
+            gen_ = importlib.import_module("qwen3_asr_mlx_amd.generate")
             side = _side_stream(dev)
             side.wait_stream(torch.cuda.current_stream())
+            steps, done = args.ndec - 1, 1
             with torch.cuda.stream(side):
                 dec_.decode_step(ws, cache, sampling)
                 dec_.capture_step(ws, cache, sampling)
-                for _ in range(args.ndec - 2):
-                    dec_.replay_step(ws)
+                checked = done
+                while done < steps:
+                    done += dec_.replay_step(ws, multi=steps - done >= dec_.MULTI_STEPS)
+                    if done - checked >= gen_.FINISH_CHECK_EVERY:
+                        checked = done
+                        gen_._all_finished(ws)
+                side.synchronize()                        # before the cross-stream wait: a parked stream slows the running one
             torch.cuda.current_stream().wait_stream(side)
         _, t_dec = timed(decode)
         secs = args.clip_seconds / 30.0
@@ -469,7 +477,7 @@ def main() -> None:
             "prefill_frac_of_2.5PF": B * 1170e9 * (T_avg / 408.0) / t_pre / 2.5e15,
             "decode_ms": 1e3 * t_dec, "decode_ms_per_token": 1e3 * t_dec / (args.ndec - 1),
             "decode_GBps": dec_bytes / t_dec / 1e9, "decode_frac_of_8TBps": dec_bytes / t_dec / 8e12,
-            "note": "one step re-run stage by stage with a device sync between stages; work figures: SURVEY.md 8d "
+            "note": "one step re-run stage by stage with a device sync between stages (decode: the product loop, 4-step graph replays); work figures: SURVEY.md 8d "
                     "(encoder 374.1 GFLOP and prefill 1,170 GFLOP per 30 s clip, decode 3.441 GB weights + B*L*114,688 B KV per token)",
         }
         log("stages: " + ", ".join(f"{k}={v:.1f}" for k, v in line["stages"].items() if k.endswith("_ms")))
