@@ -208,8 +208,13 @@ class ContinuousTranscriber:
                             if stop:
                                 break
                             continue
+                        # Hand the batch over when its encoder pass has FINISHED, not when it has been issued: the scheduler's
+                        # stream would otherwise wait for this one on the device, and a stream parked on another is a blocked
+                        # hardware queue that slows every kernel of the decode steps running beside it (~0.5 us each, DESIGN.md
+                        # section 5) -- and the admission that follows would stall the running rows until the features exist.
                         ev = torch.cuda.Event()
                         ev.record(torch.cuda.current_stream())
+                        ev.synchronize()
                         self._enc_q.put((items, ev))
                     if stop:
                         break
