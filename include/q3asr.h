@@ -181,21 +181,6 @@ int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_slabs, int6
                             const int32_t* pos, void* out16, int B, int nh, int nkv, int head_dim, int Lmax,
                             float scale, void* workspace, void* stream);
 
-/* Small batches (B <= 2): the same attention cut into the wave partials of its reduction tree (decoder.py:140-163 at T = 1).
- * One single-wave workgroup per (kv head, sequence, 1,024-token chunk, partial w = the 32-key tiles w, w + 8, ... of the chunk)
- * writes (numerator[128], max, sum) per query head to `wpart` (q3asr_attn_decode_split_workspace bytes, no initialisation
- * needed); q3asr_skinny4_gemm_attn -- the o projection (decoder.py:165) -- merges them in its prologue in the order
- * q3asr_attn_decode_fused merges them: the pair is bit-identical to q3asr_attn_decode_fused + q3asr_skinny4_gemm and spreads a
- * batch-1 step's K/V stream over 64 CUs instead of 8. */
-int64_t q3asr_attn_decode_split_workspace(int B, int nkv, int Lmax);
-int q3asr_attn_decode_split(const float* qkv_slab, int64_t ld, int n_slabs, int64_t slab_stride, const void* qn_w,
-                            const void* kn_w, const float* inv_freq, float eps, void* k_cache, void* v_cache,
-                            const int32_t* pos, int B, int nh, int nkv, int head_dim, int Lmax, float scale, void* wpart,
-                            void* stream);
-/* geometry (tiles, k-steps, waves) = (2, 2, 8) only: K = 2 * nkv * 128 = 256 * waves */
-int q3asr_skinny4_gemm_attn(const float* wpart, const int32_t* pos, int nkv, int Lmax, int M, const void* W16, int N, int K,
-                            int tiles_per_wg, int ksteps_per_wave, int waves, float* slab, void* stream);
-
 /* ---- generate.py:88-215 `sample` + loop bookkeeping :286-313, one launch per step ------------ */
 /* finished[b]: 0 running, 1 ended (EOS or budget), Q3ASR_ROW_FAILED: the row's logits had no valid maximum / draw (non-finite
  * logits).  A failed row records token 0 and stops; the host raises when it reads the flag (generate.py). */

@@ -43,9 +43,6 @@ _SIGS = {
     "q3asr_attn_decode_fused_workspace": [_i, _i, _i],
     "q3asr_attn_decode_set_chunks_per_wg": [_i],
     "q3asr_attn_decode_fused": [_vp, _i64, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
-    "q3asr_attn_decode_split_workspace": [_i, _i, _i],
-    "q3asr_attn_decode_split": [_vp, _i64, _i, _i64, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
-    "q3asr_skinny4_gemm_attn": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "q3asr_sample_step": [_vp, _i64, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _i, _u64, _i, _i, _i, _vp],
     "q3asr_graph_begin": [_vp],
     "q3asr_graph_end": [_vp, C.POINTER(_vp)],
@@ -58,8 +55,7 @@ _SIGS = {
     "q3asr_event_elapsed_ms": [_vp, _vp, C.POINTER(_f)],
     "q3asr_event_destroy": [_vp],
 }
-_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p, "q3asr_attn_decode_fused_workspace": C.c_int64,
-             "q3asr_attn_decode_split_workspace": C.c_int64}
+_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p, "q3asr_attn_decode_fused_workspace": C.c_int64}
 EXPORTS = tuple(_SIGS)
 
 

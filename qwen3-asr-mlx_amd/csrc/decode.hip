@@ -42,8 +42,6 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(unsigned lo, unsigned hi) {
     return r;
 }
 
-#define ADF_CHUNK 1024                // tokens per chunk of the decode attention's reduction tree (attn_decode_fused_kernel)
-
 // FUSE (M <= 2, 256 threads): the activation operand is not read from X16 but built by every workgroup for itself from
 // the previous GEMM's split-K slabs -- h = bf16(h + bf16(sum slabs)), x = RMSNorm(h) * w, the arithmetic of
 // slab_resnorm_x16_kernel thread for thread (bit-identical) -- into LDS rows, while the first weight tiles are
@@ -52,9 +50,6 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(unsigned lo, unsigned hi) {
 struct FuseNorm {
     const float* slab; int S; long stride;
     const bf16* h_in; bf16* h_out; const bf16* w; float eps;
-    // FUSE = 2 (the o projection at M <= 2): the operand is the attention output, merged here from the wave partials
-    // attn_decode_split_kernel wrote: apart [M][nkv][anc][8][2][130] fp32, apos = the sequences' positions
-    const float* apart; const int* apos; int anc; int nkv;
 };
 
 __device__ __forceinline__ void fuse_norm_prologue(const FuseNorm& f, int M, int K, bf16* xl, float* hl, float* fred, bool writer) {
@@ -376,41 +371,13 @@ extern "C" int q3asr_skinny3_gemm_norm(const float* in_slab, int in_n_slabs, int
 // ---------------------------------------------------------------------------
 // FUSE (M <= 2): the X fragments come from LDS rows that every workgroup builds for itself from the previous GEMM's slabs
 // (fuse_norm_prologue, the arithmetic of slab_resnorm_x16_kernel) while its weights are in flight.
-// FUSE = 2 (M <= 2, K = 64 * WAVES * 4 columns): the X fragments are the attention output, merged by every workgroup for itself
-// from the wave partials of attn_decode_split_kernel (fuse_attn_merge: the merge of attn_decode_fused_kernel, same order,
-// same bits); a thread's chunk-0 partials are requested BEFORE its weight loads so that they return first.
-__device__ __forceinline__ void fuse_attn_merge8(const f32x4 (&pa)[8], const float (&pm)[8], const float (&pl)[8], f32x4& num, float& Mx, float& den) {
-    Mx = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) Mx = fmaxf(Mx, pm[w]);
-    num = f32x4{0.f, 0.f, 0.f, 0.f};
-    den = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const float wgt = __expf(pm[w] - Mx);              // a partial without tiles holds (-inf, 0, 0): weight 0
-#pragma unroll
-        for (int r = 0; r < 4; ++r) num[r] = fmaf(pa[w][r], wgt, num[r]);
-        den = fmaf(pl[w], wgt, den);
-    }
-}
-__device__ __forceinline__ void fuse_attn_load8(const float* base, int d4, f32x4 (&pa)[8], float (&pm)[8], float (&pl)[8]) {
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const float* q = base + (long)w * (2 * 130);
-        pa[w] = *reinterpret_cast<const f32x4*>(q + d4);
-        pm[w] = q[128];
-        pl[w] = q[129];
-    }
-}
-
-template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, int FUSE = 0>
+template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, bool FUSE = false>
 __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restrict__ X16, const void* __restrict__ Wt, int M, int N, int K,
                                                              const float* __restrict__ w_scale, float* __restrict__ slab,
                                                              bf16* __restrict__ out, long ldo, const FuseNorm fz) {
     static_assert(!F8 || NKS % 2 == 0, "fp8 fragments come in pairs of k steps");
     static_assert(EPI != 2 || TPW % 2 == 0, "SwiGLU needs whole (gate, up) tile pairs per workgroup");
     static_assert(!FUSE || (MT == 1 && WAVES >= 4), "fused norm: M <= 2, at least 256 threads");
-    static_assert(FUSE != 2 || (WAVES == 8 && EPI == 0 && !F8), "fused attention merge: the o projection's geometry (512 threads = 2048 columns / 4)");
     extern __shared__ f32x4 red4[];                          // [WAVES][TPW][MT][64] | FUSE: x rows [2][K] bf16 | K floats
     __shared__ float fred4[4];
     constexpr int MC = MT < 2 ? MT : 2;                      // m-tiles per pass
@@ -429,15 +396,6 @@ __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restr
 #pragma unroll
             for (int mc = 0; mc < MC; ++mc) xf[i][mc] = *reinterpret_cast<const bf16x8*>(xp + ((long)i * MT + mc) * 512);
     }
-    // FUSE = 2: thread -> (query head, 4 consecutive dims); chunk-0 partials of rows 0 and 1
-    const int ahq = threadIdx.x >> 5, ad4 = (threadIdx.x & 31) * 4;
-    f32x4 apa[FUSE == 2 ? 2 : 1][8];
-    float apm[FUSE == 2 ? 2 : 1][8], apl[FUSE == 2 ? 2 : 1][8];
-    if constexpr (FUSE == 2) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-            if (m < M) fuse_attn_load8(fz.apart + ((((long)m * fz.nkv + (ahq >> 1)) * fz.anc) * 8) * (2 * 130) + (ahq & 1) * 130, ad4, apa[m], apm[m], apl[m]);
-    }
     if constexpr (!F8) {
         const bf16* wp = (const bf16*)Wt + ((long)t0 * (K >> 5) + ks0) * 512 + lane * 8;
 #pragma unroll
@@ -454,58 +412,10 @@ __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restr
                 w8[i][t] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + ((long)t * (K >> 6) + i) * 1024));
     }
     __builtin_amdgcn_sched_barrier(0);                       // every load above is issued before the first MFMA below
-    if constexpr (FUSE != 0) {
+    if constexpr (FUSE) {
         bf16* xl = reinterpret_cast<bf16*>(red4 + WAVES * TPW * MT * 64);
-        if constexpr (FUSE == 1) {
-            float* hl = reinterpret_cast<float*>(reinterpret_cast<char*>(xl) + (size_t)K * 4);
-            fuse_norm_prologue(fz, M, K, xl, hl, fred4, blockIdx.x == 0 && blockIdx.y == 0);
-        } else {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                if (m >= M) break;
-                const int n_active = (fz.apos[m] + 1 + ADF_CHUNK - 1) / ADF_CHUNK;
-                const float* base = fz.apart + ((((long)m * fz.nkv + (ahq >> 1)) * fz.anc) * 8) * (2 * 130) + (ahq & 1) * 130;
-                f32x4 num; float Mx, den;
-                fuse_attn_merge8(apa[m], apm[m], apl[m], num, Mx, den);
-                f32x4 o;
-                if (n_active == 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = num[r] / den;
-                } else {                                     // chunks merged in chunk order: max over the chunks first, then the weighted sums
-                    float Mall = Mx;
-                    for (int c = 1; c < n_active; ++c) {
-                        const float* q = base + (long)c * 8 * (2 * 130);
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) Mall = fmaxf(Mall, q[(long)w * (2 * 130) + 128]);
-                    }
-                    f32x4 N = f32x4{0.f, 0.f, 0.f, 0.f};
-                    float D = 0.f;
-                    {
-                        const float wc = __expf(Mx - Mall);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) N[r] = fmaf(num[r], wc, N[r]);
-                        D = fmaf(den, wc, D);
-                    }
-                    for (int c = 1; c < n_active; ++c) {
-                        f32x4 pa[8]; float pm[8], pl[8];
-                        fuse_attn_load8(base + (long)c * 8 * (2 * 130), ad4, pa, pm, pl);
-                        f32x4 nc_; float Mc, dc;
-                        fuse_attn_merge8(pa, pm, pl, nc_, Mc, dc);
-                        const float wc = __expf(Mc - Mall);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) N[r] = fmaf(nc_[r], wc, N[r]);
-                        D = fmaf(dc, wc, D);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = N[r] / D;
-                }
-                bf16x4 ob;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ob[r] = f2bf(o[r]);
-                *reinterpret_cast<bf16x4*>(xl + (long)m * K + ahq * 128 + ad4) = ob;
-            }
-            __syncthreads();
-        }
+        float* hl = reinterpret_cast<float*>(reinterpret_cast<char*>(xl) + (size_t)K * 4);
+        fuse_norm_prologue(fz, M, K, xl, hl, fred4, blockIdx.x == 0 && blockIdx.y == 0);
         const int xrow = min(lane & 15, M - 1) * K + 8 * (lane >> 4);      // lanes of rows >= M re-read the last row (results unused)
 #pragma unroll
         for (int i = 0; i < NKS; ++i) xf[i][0] = *reinterpret_cast<const bf16x8*>(xl + xrow + (ks0 + i) * 32);
@@ -590,7 +500,7 @@ __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restr
     }
 }
 
-template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, int FUSE>
+template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, bool FUSE>
 static void skinny4_go(dim3 grid, hipStream_t s, const void* X16, const FuseNorm& fz, const void* W, int M, int N, int K, const float* w_scale,
                        float* slab, void* out, long ldo) {
     constexpr size_t image = (size_t)WAVES * TPW * MT * 64 * sizeof(f32x4);
@@ -623,18 +533,12 @@ static int skinny4_launch(const char* who, const void* X16, const FuseNorm* fuse
     if (epi == 1) Q3_REQUIRE(ldo % 4 == 0 && ldo >= N, "%s: bad ldo", who);
     if (w_scale) Q3_REQUIRE(ksteps_per_wave % 2 == 0, "%s: fp8 weights need an even number of k-steps per wave", who);
     FuseNorm fz{};
-    const int fuse_kind = !fuse ? 0 : (fuse->apart ? 2 : 1);
-    if (fuse_kind == 1) {
+    if (fuse) {
         fz = *fuse;
         Q3_REQUIRE(M <= 2 && epi != 1, "%s: fused norm needs M <= 2, epi 0 or 2", who);
         Q3_REQUIRE(fz.slab && fz.S >= 1 && fz.h_in && fz.h_out && fz.w && fz.h_in != fz.h_out && fz.slab != slab,
                    "%s: fused norm needs its own input slabs and distinct h_in / h_out", who);
         Q3_REQUIRE(K % 8 == 0 && (size_t)waves * tiles_per_wg * 1024 + (size_t)K * 8 <= 160 * 1024, "%s: K=%d too large for the fused activation image", who, K);
-    } else if (fuse_kind == 2) {
-        fz = *fuse;
-        Q3_REQUIRE(M <= 2 && epi == 0 && !w_scale, "%s: fused attention merge needs M <= 2, the slab epilogue and bf16 weights", who);
-        Q3_REQUIRE(fz.apos && fz.anc > 0 && fz.nkv > 0 && K == 2 * fz.nkv * 128 && K == 256 * waves,
-                   "%s: fused attention merge needs K = 2 * nkv * 128 = 256 * waves (K=%d, nkv=%d, waves=%d)", who, K, fz.nkv, waves);
     }
     const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     dim3 grid(N / 16 / tiles_per_wg, S);
@@ -642,7 +546,7 @@ static int skinny4_launch(const char* who, const void* X16, const FuseNorm* fuse
     bool done = false;
 #define Q3_TRY(MT_, TPW_, NKS_, EPI_, WAVES_, F8_, FUSE_)                                                                              \
     if (!done && MT == MT_ && tiles_per_wg == TPW_ && ksteps_per_wave == NKS_ && epi == EPI_ && waves == WAVES_ && (w_scale != nullptr) == F8_ && \
-        fuse_kind == (int)(FUSE_)) {                                                                                                  \
+        (fuse != nullptr) == FUSE_) {                                                                                                  \
         skinny4_go<MT_, TPW_, NKS_, EPI_, WAVES_, F8_, FUSE_>(grid, s, X16, fz, W16, M, N, K, w_scale, slab, out, (long)ldo);          \
         done = true;                                                                                                                   \
     }
@@ -658,7 +562,6 @@ static int skinny4_launch(const char* who, const void* X16, const FuseNorm* fuse
     Q3_TRY_MT(2, 2, 8, 0) Q3_TRY_MT(2, 4, 8, 0) Q3_TRY_MT(2, 6, 8, 0) Q3_TRY_MT(2, 3, 16, 0)
     Q3_TRY_MT(2, 2, 8, 1) Q3_TRY_MT(2, 8, 8, 1) Q3_TRY_MT(4, 8, 8, 1)
     Q3_TRY_MT(2, 2, 8, 2) Q3_TRY_MT(4, 4, 16, 2) Q3_TRY_MT(2, 4, 16, 2)
-    Q3_TRY(1, 2, 2, 0, 8, false, 2)                          // the o projection with the attention merge in its prologue
 #undef Q3_TRY_MT
 #undef Q3_TRY_F8
 #undef Q3_TRY
@@ -672,20 +575,10 @@ extern "C" int q3asr_skinny4_gemm(const void* X16, int M, const void* W16, const
     return skinny4_launch("skinny4_gemm", X16, nullptr, M, W16, w_scale, N, K, epi, tiles_per_wg, ksteps_per_wave, waves, slab, out, ldo, stream);
 }
 
-// q3asr_skinny4_gemm for the o projection at M <= 2 with the merge of the decode attention's wave partials in its prologue
-// (q3asr_attn_decode_split wrote them): slabs bit-identical to q3asr_attn_decode_fused followed by q3asr_skinny4_gemm.
-extern "C" int q3asr_skinny4_gemm_attn(const float* wpart, const int32_t* pos, int nkv, int Lmax, int M, const void* W16, int N, int K,
-                                       int tiles_per_wg, int ksteps_per_wave, int waves, float* slab, void* stream) {
-    Q3_REQUIRE(wpart && pos && Lmax > 0, "skinny4_gemm_attn: null pointer");
-    FuseNorm f{};
-    f.apart = wpart; f.apos = pos; f.anc = (Lmax + ADF_CHUNK - 1) / ADF_CHUNK; f.nkv = nkv;
-    return skinny4_launch("skinny4_gemm_attn", nullptr, &f, M, W16, nullptr, N, K, 0, tiles_per_wg, ksteps_per_wave, waves, slab, nullptr, 0, stream);
-}
-
 extern "C" int q3asr_skinny4_gemm_norm(const float* in_slab, int in_n_slabs, int64_t in_slab_stride, const void* h_in, void* h_out,
                                        const void* norm_w, float eps, int M, const void* W16, const float* w_scale, int N, int K, int epi,
                                        int tiles_per_wg, int ksteps_per_wave, int waves, float* slab, void* out, int64_t ldo, void* stream) {
-    FuseNorm f{in_slab, in_n_slabs, (long)in_slab_stride, (const bf16*)h_in, (bf16*)h_out, (const bf16*)norm_w, eps, nullptr, nullptr, 0, 0};
+    FuseNorm f{in_slab, in_n_slabs, (long)in_slab_stride, (const bf16*)h_in, (bf16*)h_out, (const bf16*)norm_w, eps};
     return skinny4_launch("skinny4_gemm_norm", nullptr, &f, M, W16, w_scale, N, K, epi, tiles_per_wg, ksteps_per_wave, waves, slab, out, ldo, stream);
 }
 
@@ -883,6 +776,7 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, vo
 // a 500-token context): batch-1 latency 180.5 vs 180.0 ms -- the dependent chain (slab sum -> QK-norm -> RoPE -> one tile
 // per wave -> merge) is what a batch-1 launch costs, and the cross-workgroup merge adds a ticket round trip -- and the
 // batch-32 step lost 3.7 % to the extra per-chunk barriers.
+#define ADF_CHUNK 1024
 #define ADF_LOCAL_MAX 8               // chunks whose partials fit the LDS array below
 #define ADF_PART (2 * 130)            // floats per (sequence, kv head, chunk): per head 128 numerators, max, sum
 
@@ -1115,6 +1009,10 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             }
             if (ce < t_endm) __syncthreads();                              // the partials are rewritten by the next chunk
         }
+#undef ADM_SOFTMAX_PV
+#undef ADM_STAGE_QK
+#undef ADM_LOAD
+#undef ADM_LD
     }
     if (n_active == 1) return;                                        // uniform
     const int h = (tid >> 7) & 1, d = tid & 127;
@@ -1159,170 +1057,6 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     }
     if (n_groups > 1 && tid == 0)
         __hip_atomic_store(counters + b * nkv + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-}
-
-
-// ---------------------------------------------------------------------------
-// Small batches (M <= 2): the same attention cut into its wave partials.  attn_decode_fused_kernel puts one 512-thread
-// workgroup on each (kv head, sequence): at batch 1 that is 8 workgroups pulling 242 KB each (a 470-token context) through
-// 8 CUs' memory pipes at the ~35-40 GB/s one CU gets -- 9.3 us of a 38 us layer (profiles/r03_decode_graph_trace_b1.txt),
-// against 13.5 us for the same kernel at batch 32 where 256 CUs share the work.  The reduction tree, however, is fixed by the
-// sequence alone: chunk c of 1,024 tokens = 8 partials, partial w = the online softmax over the 32-key tiles w, w + 8, ... of
-// the chunk.  Here every partial is a workgroup of its own (ONE wave; grid (kv heads, sequences, chunks x 8)): it runs the
-// prologue it needs (both query heads; k / v of the new token only where its tiles hold that token), sweeps its tiles with
-// the macros of the kernel above, and writes (numerator[128], max, sum) per head to `wpart`.  The merge -- per chunk over the
-// 8 partials in wave order, then over the chunks in chunk order, the arithmetic of the kernel above -- runs in the prologue
-// of the o projection that consumes the result (skinny4_kernel<..., FUSE = 2>, fuse_attn_prologue), so no workgroup waits
-// for another and the tree, hence every bit, is the one of the 512-thread kernel.
-// wpart: [B][nkv][nc][8 partials][2 heads][130] fp32 (q3asr_attn_decode_split_workspace), fully rewritten for the chunks
-// a launch covers; chunks beyond a sequence's length are never read.
-// ---------------------------------------------------------------------------
-#define ADS_PART 130
-
-// One prologue role for the wave: the fixed-order slab sum of 128 columns (two per lane), then RMSNorm x RoPE (q / k) or
-// the plain bf16 row (v): the statements of attn_decode_fused_kernel's prologue.
-struct AdsRow { float x1, x2; };
-__device__ __forceinline__ AdsRow ads_slab_sum(const float* __restrict__ src, int n_slabs, long slab_stride, int lane) {
-    float p1[8], p2[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const bool in = u < n_slabs;
-        p1[u] = in ? src[u * slab_stride + lane] : 0.f;
-        p2[u] = in ? src[u * slab_stride + lane + 64] : 0.f;
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { s1 += p1[u]; s2 += p2[u]; }
-    for (int s0 = 8; s0 < n_slabs; s0 += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool in = s0 + u < n_slabs;
-            p1[u] = in ? src[(s0 + u) * slab_stride + lane] : 0.f;
-            p2[u] = in ? src[(s0 + u) * slab_stride + lane + 64] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += p1[u]; s2 += p2[u]; }
-    }
-    return AdsRow{round_bf(s1), round_bf(s2)};
-}
-__device__ __forceinline__ AdsRow ads_norm_rope(AdsRow x, bf16 nw1, bf16 nw2, float eps, float ang) {
-    const float ss = wave_sum(x.x1 * x.x1 + x.x2 * x.x2) * (1.0f / 128.0f);
-    const float r = rsqrtf(ss + eps);
-    const float y1 = round_bf(x.x1 * r * bf2f(nw1)), y2 = round_bf(x.x2 * r * bf2f(nw2));
-    float sn, cs;
-    sincosf(ang, &sn, &cs);
-    return AdsRow{round_bf(y1 * cs - y2 * sn), round_bf(y1 * sn + y2 * cs)};
-}
-
-template <bool NT>
-__global__ __launch_bounds__(64) void attn_decode_split_kernel(const float* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
-                                                               const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
-                                                               const float* __restrict__ inv_freq, float eps,
-                                                               bf16* __restrict__ k_cache, bf16* __restrict__ v_cache,
-                                                               const int* __restrict__ pos_arr, int nh, int nkv, int Lmax, float scale,
-                                                               float* __restrict__ wpart, int nc) {
-    __shared__ __attribute__((aligned(16))) bf16 s_qb[2][128];
-    __shared__ __attribute__((aligned(16))) bf16 s_k[128], s_v[128];
-    __shared__ __attribute__((aligned(16))) char s_vt[8192];             // this wave's 32-key V tile
-    const int kvh = blockIdx.x, b = blockIdx.y;
-    const int chunk = blockIdx.z >> 3, wave = blockIdx.z & 7;           // the partial this workgroup computes
-    const int pos = pos_arr[b];
-    const int L = pos + 1, n_active = (L + ADF_CHUNK - 1) / ADF_CHUNK;
-    if (chunk >= n_active) return;
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, i = lane & 15;
-    bf16* Kb = k_cache + ((long)b * nkv + kvh) * Lmax * 128;
-    bf16* Vb = v_cache + ((long)b * nkv + kvh) * Lmax * 128;
-    const int cb = chunk * ADF_CHUNK, ce = min(L, cb + ADF_CHUNK);
-    const int t_last = pos > 0 ? pos - 1 : 0;
-    // the new token sits in tile (pos % 1024) / 32 of the last chunk, which partial ((pos % 1024) / 32) % 8 sweeps
-    const bool kv_owner = chunk == n_active - 1 && (((pos - cb) >> 5) & 7) == wave;
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const int li = i;
-    bf16x8 kR[2][4];
-    u32x4 vR[8];
-    int tb = cb + 32 * wave;
-    // prologue loads first (a wave's loads return in order), then the first tile's keys and values
-    const float* qsrc = qkv + (long)b * ld;
-    const AdsRow q0 = ads_slab_sum(qsrc + (2 * kvh) * 128, n_slabs, slab_stride, lane);
-    const AdsRow q1 = ads_slab_sum(qsrc + (2 * kvh + 1) * 128, n_slabs, slab_stride, lane);
-    AdsRow kx{0.f, 0.f}, vx{0.f, 0.f};
-    if (kv_owner) {
-        kx = ads_slab_sum(qsrc + (nh + kvh) * 128, n_slabs, slab_stride, lane);
-        vx = ads_slab_sum(qsrc + (nh + nkv + kvh) * 128, n_slabs, slab_stride, lane);
-    }
-    const bf16 qw1 = qn_w[lane], qw2 = qn_w[lane + 64], kw1 = kn_w[lane], kw2 = kn_w[lane + 64];
-    const float ang = (float)pos * inv_freq[lane];
-    if (tb < ce) { ADM_LOAD(kR, vR, tb) }
-    {
-        const AdsRow a = ads_norm_rope(q0, qw1, qw2, eps, ang), c = ads_norm_rope(q1, qw1, qw2, eps, ang);
-        s_qb[0][lane] = f2bf(a.x1); s_qb[0][lane + 64] = f2bf(a.x2);
-        s_qb[1][lane] = f2bf(c.x1); s_qb[1][lane + 64] = f2bf(c.x2);
-        if (kv_owner) {
-            const AdsRow k = ads_norm_rope(kx, kw1, kw2, eps, ang);
-            const bf16 k1 = f2bf(k.x1), k2 = f2bf(k.x2), v1 = f2bf(vx.x1), v2 = f2bf(vx.x2);
-            s_k[lane] = k1; s_k[lane + 64] = k2;
-            Kb[(long)pos * 128 + lane] = k1; Kb[(long)pos * 128 + lane + 64] = k2;
-            s_v[lane] = v1; s_v[lane + 64] = v2;
-            Vb[(long)pos * 128 + lane] = v1; Vb[(long)pos * 128 + lane + 64] = v2;
-        }
-    }
-    __syncthreads();                                                    // one wave: orders the LDS writes above before the reads below
-    const int q4 = li >> 2, p4 = li & 3;
-    char* sVw = s_vt;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = bf16x8{};
-        if (li < 2) qf[ks] = *reinterpret_cast<const bf16x8*>(&s_qb[li][32 * ks + 8 * g]);
-    }
-    f32x4 o_[8];
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o_[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    for (; tb < ce; tb += 256) {
-        f32x4 sc_[2];
-        ADM_STAGE_QK(kR, vR, tb)
-        if (tb + 256 < ce) { ADM_LOAD(kR, vR, tb + 256) }
-        ADM_SOFTMAX_PV(tb)
-    }
-    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
-    if (li < 2) {                                                       // lane column li = query head li of this kv head
-        float* dst = wpart + ((((long)b * nkv + kvh) * nc + chunk) * 8 + wave) * (2 * ADS_PART) + li * ADS_PART;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(dst + 16 * dt + 4 * g) = o_[dt];
-        if (g == 0) { dst[128] = m_run; dst[129] = l_tot; }
-    }
-}
-#undef ADM_SOFTMAX_PV
-#undef ADM_STAGE_QK
-#undef ADM_LOAD
-#undef ADM_LD
-
-extern "C" int64_t q3asr_attn_decode_split_workspace(int B, int nkv, int Lmax) {
-    if (B <= 0 || nkv <= 0 || Lmax <= 0) return 0;
-    const int64_t nc = (Lmax + ADF_CHUNK - 1) / ADF_CHUNK;
-    return (int64_t)B * nkv * nc * 8 * 2 * ADS_PART * 4;
-}
-
-extern "C" int q3asr_attn_decode_split(const float* qkv_slab, int64_t ld, int n_slabs, int64_t slab_stride, const void* qn_w, const void* kn_w,
-                                       const float* inv_freq, float eps, void* k_cache, void* v_cache, const int32_t* pos, int B, int nh, int nkv,
-                                       int head_dim, int Lmax, float scale, void* wpart, void* stream) {
-    Q3_REQUIRE(qkv_slab && n_slabs > 0 && qn_w && kn_w && inv_freq && k_cache && v_cache && pos && wpart, "attn_decode_split: null pointer");
-    Q3_REQUIRE(head_dim == 128 && nh == 2 * nkv, "attn_decode_split: needs head_dim 128 and 2 query heads per kv head");
-    Q3_REQUIRE(B > 0 && B <= 2 && Lmax > 0 && ld >= (int64_t)(nh + 2 * nkv) * 128, "attn_decode_split: B=%d must be 1 or 2 (the merge runs in q3asr_skinny4_gemm_attn)", B);
-    const int nc = (Lmax + ADF_CHUNK - 1) / ADF_CHUNK;
-    Q3_REQUIRE(nc * 8 <= 65535, "attn_decode_split: Lmax=%d too long", Lmax);
-    const bool nt = (int64_t)B * nkv * Lmax * 512 > (16LL << 20);      // as q3asr_attn_decode_fused
-    const dim3 grid(nkv, B, nc * 8);
-    if (nt)
-        hipLaunchKernelGGL(attn_decode_split_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
-                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, nh, nkv, Lmax, scale, (float*)wpart, nc);
-    else
-        hipLaunchKernelGGL(attn_decode_split_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
-                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, nh, nkv, Lmax, scale, (float*)wpart, nc);
-    return q3_check_launch("attn_decode_split");
 }
 
 static int g_attn_chunks_per_wg = 0;

@@ -44,7 +44,6 @@ class KVCache:
         self.batch = 0
         self.max_len = 0
         self.attn_ws = None        # q3asr_attn_decode_fused workspace (chunk partials + arrival counters), zeroed once
-        self.attn_split_ws = None  # q3asr_attn_decode_split wave partials (batch <= 2)
 
     def ensure(self, cfg: TextDecoderConfig, batch: int, max_len: int, device) -> None:
         import torch
@@ -59,10 +58,6 @@ class KVCache:
             self.batch, self.max_len = batch, max_len
             nbytes = _lib.load().q3asr_attn_decode_fused_workspace(batch, cfg.num_key_value_heads, max_len)
             self.attn_ws = torch.zeros((nbytes // 4,), dtype=torch.float32, device=device)
-            self.attn_split_ws = None
-            if batch <= 2:
-                nbytes = _lib.load().q3asr_attn_decode_split_workspace(batch, cfg.num_key_value_heads, max_len)
-                self.attn_split_ws = torch.zeros((nbytes // 4,), dtype=torch.float32, device=device)
 
     @property
     def keys(self):
@@ -176,7 +171,6 @@ class TextDecoder:
         self.geo4_override: dict = {}    # launch geometries by GEMM name (tools/tune_decode.py); applies to workspaces created afterwards
         self.fuse_norm = True        # batch <= 2: residual + RMSNorm inside the consuming qkv GEMM (False: separate launches, A/B; tools/ab_batch1.py)
         self.fuse_norm_gu = True     # ... and inside gate/up too
-        self.split_attn = True       # batch <= 2: the decode attention as 64 single-wave workgroups per sequence, merged in the o projection's prologue (False: A/B)
         self._caches: dict = {}
         self._api_ws = None
 
@@ -468,28 +462,16 @@ class TextDecoder:
             # next layer's qkv, whose own slabs go to ws.slab2 (a kernel must not write the buffer its neighbours still read);
             # the residual stream ping-pongs between ws.h and ws.h2 for the same reason.
             h_cur, h_oth, s_d = ws.h, ws.h2, 0
-            # the split attention needs the o projection's (2, 2, 8) skinny4 geometry, bf16 weights and 2 query heads per kv head
-            split = (self.split_attn and self.decode_gemm == "sk4" and ws.geo4.get("o") == (2, 2, 8) and hd == 128 and nh == 2 * nkv
-                     and layers[0]["wo_s"] is None and qd == 256 * 8 and cache.attn_split_ws is not None)
             for li, L in enumerate(layers):
                 if li == 0:
                     s_qkv = self._gemm3(ws, "qkv", ws.x16, L, "wqkv", qkvd, H, 0, slab=ws.slab2)
                 else:
                     s_qkv = self._gemm3_norm(ws, "qkv", ws.slab, s_d, h_cur, h_oth, L["ln1"], L, "wqkv", qkvd, H, 0, slab=ws.slab2)
                     h_cur, h_oth = h_oth, h_cur
-                if split:
-                    # 64 single-wave workgroups per sequence write the wave partials of the attention's reduction tree; the o
-                    # projection merges them in its prologue (same tree, same bits as the 512-thread kernel + plain GEMM)
-                    ops.call("q3asr_attn_decode_split", ops.ptr(ws.slab2), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),
-                             ops.ptr(w["inv_freq"]), eps, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(pos),
-                             B, nh, nkv, hd, Lmax, scale, ops.ptr(cache.attn_split_ws), ops.sp())
-                    ops.skinny4_attn(cache.attn_split_ws, pos, nkv, Lmax, B, L["wo16"], H, qd, *ws.geo4["o"], slab=ws.slab)
-                    s_o = qd // (32 * ws.geo4["o"][1] * ws.geo4["o"][2])
-                else:
-                    ops.call("q3asr_attn_decode_fused", ops.ptr(ws.slab2), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),
-                             ops.ptr(w["inv_freq"]), eps, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(pos), ops.ptr(ws.att16),
-                             B, nh, nkv, hd, Lmax, scale, ops.ptr(cache.attn_ws), ops.sp())
-                    s_o = self._gemm3(ws, "o", ws.att16, L, "wo", H, qd, 0)
+                ops.call("q3asr_attn_decode_fused", ops.ptr(ws.slab2), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),
+                         ops.ptr(w["inv_freq"]), eps, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(pos), ops.ptr(ws.att16),
+                         B, nh, nkv, hd, Lmax, scale, ops.ptr(cache.attn_ws), ops.sp())
+                s_o = self._gemm3(ws, "o", ws.att16, L, "wo", H, qd, 0)
                 if self.fuse_norm_gu:
                     self._gemm3_norm(ws, "gu", ws.slab, s_o, h_cur, h_oth, L["ln2"], L, "wgu", 2 * I, H, 2, out=ws.act16)
                     h_cur, h_oth = h_oth, h_cur
@@ -557,8 +539,7 @@ class TextDecoder:
         # its large K/V blocks back from the caching allocator while the small workspace lands elsewhere -- and every switch
         # that changes which launches are recorded)
         key = (cache.k.data_ptr(), cache.v.data_ptr(), cache.attn_ws.data_ptr(), cache.max_len, self.decode_gemm,
-               bool(self.fuse_norm), bool(self.fuse_norm_gu), bool(self.split_attn),
-               cache.attn_split_ws.data_ptr() if cache.attn_split_ws is not None else 0, tuple(sorted(sampling.items())))
+               bool(self.fuse_norm), bool(self.fuse_norm_gu), tuple(sorted(sampling.items())))
         if ws.graph is not None and ws.graph_key == key:
             ws.graph_uses += 1
             if ws.graph_multi is None and ws.graph_uses >= 2:        # a workspace that keeps coming back earns the long graph

@@ -124,11 +124,6 @@ def skinny4_norm(in_slab, in_n_slabs, in_stride, h_in, h_out, norm_w, eps, M, W1
          N, K, epi, tpw, nks, waves, ptr(slab), ptr(out), ldo if ldo is not None else N, sp())
 
 
-def skinny4_attn(wpart, pos, nkv, Lmax, M, W16, N, K, tpw, nks, waves, slab):
-    """The o projection at M <= 2 with the merge of q3asr_attn_decode_split's wave partials in its prologue."""
-    call("q3asr_skinny4_gemm_attn", ptr(wpart), ptr(pos), nkv, Lmax, M, ptr(W16), N, K, tpw, nks, waves, ptr(slab), sp())
-
-
 def pick_splits3(N: int, K: int, waves: int = 4) -> int:
     """Smallest split-K factor that gives >= 256 workgroups (one per CU), K slice >= 128."""
     tiles = (N // 16 + waves - 1) // waves

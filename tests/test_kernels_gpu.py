@@ -818,48 +818,6 @@ def test_attn_decode_fused_is_independent_of_batch_and_capacity(dev):
         assert torch.equal(one[0], full[j])
 
 
-@pytest.mark.parametrize("poss,S,Lmax", [([0], 2, 576), ([31], 2, 576), ([32, 5], 4, 576), ([255, 256], 2, 576), ([470], 2, 576), ([408, 535], 2, 576),
-                                          ([1023, 1024], 2, 3072), ([1500, 2900], 3, 3072), ([2047], 2, 2048)])
-def test_attn_decode_split_plus_o_merge_equals_fused_plus_o(dev, poss, S, Lmax):
-    """Batch <= 2: the decode attention cut into its wave partials (64 single-wave workgroups per sequence and chunk) with the merge
-    in the o projection's prologue == q3asr_attn_decode_fused followed by q3asr_skinny4_gemm, bit for bit: the o slabs, the cache
-    rows of the new token -- for one and several chunks, the new token in any tile / partial, ragged positions."""
-    from qwen3_asr_mlx_amd import _lib, ops
-    nh, nkv, hd, H = 16, 8, 128, 2048                          # the 1.7B attention shape (the merge prologue needs K = 2048)
-    B = len(poss)
-    qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
-    parts = rnd((S, B, qkvd), dev, 170, 1.0, torch.float32)
-    qn, kn = rnd((hd,), dev, 171) + 1, rnd((hd,), dev, 172) + 1
-    inv = (1e6 ** (-torch.arange(64, dtype=torch.float32) / 64)).to(dev)
-    kc0, vc0 = rnd((B, nkv, Lmax, hd), dev, 173), rnd((B, nkv, Lmax, hd), dev, 174)
-    Wo = rnd((H, qd), dev, 175, 1.0 / math.sqrt(qd))
-    w16 = ops.to_w16(Wo)
-    pos = torch.tensor(poss, dtype=torch.int32, device=dev)
-    tpw, nks, waves = 2, 2, 8
-    n_sl = qd // (32 * nks * waves)
-    # reference pair
-    kc1, vc1 = kc0.clone(), vc0.clone()
-    wsp = torch.zeros((_lib.load().q3asr_attn_decode_fused_workspace(B, nkv, Lmax) // 4,), dtype=torch.float32, device=dev)
-    o16 = torch.zeros((qd // 32, ops.mt_of(B), 64, 8), dtype=torch.bfloat16, device=dev)
-    ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
-             ops.ptr(kc1), ops.ptr(vc1), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
-    slab1 = torch.full((n_sl, B, H), float("nan"), dtype=torch.float32, device=dev)
-    ops.skinny4(o16, B, w16, H, qd, 0, tpw, nks, waves, slab=slab1)
-    # split pair (the partial buffer needs no initialisation: poison it)
-    nbytes = _lib.load().q3asr_attn_decode_split_workspace(B, nkv, Lmax)
-    assert nbytes == 4 * B * nkv * ((Lmax + 1023) // 1024) * 8 * 2 * 130
-    for rep in range(2):
-        kc2, vc2 = kc0.clone(), vc0.clone()
-        wp = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=dev)
-        ops.call("q3asr_attn_decode_split", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
-                 ops.ptr(kc2), ops.ptr(vc2), ops.ptr(pos), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wp), ops.sp())
-        slab2 = torch.full((n_sl, B, H), float("nan"), dtype=torch.float32, device=dev)
-        ops.skinny4_attn(wp, pos, nkv, Lmax, B, w16, H, qd, tpw, nks, waves, slab=slab2)
-        assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
-        assert torch.isfinite(slab2).all()
-        assert torch.equal(slab2, slab1)
-
-
 # ----------------------------------------------------------------------------- fp8 weights (BASELINE.json configs[4])
 def test_fp8_row_quantisation_is_exact_in_bf16(dev):
     from qwen3_asr_mlx_amd import ops
