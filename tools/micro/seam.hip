@@ -48,6 +48,7 @@ __global__ void fill_kernel(bf16* p, long n, unsigned seed, float scale) {
 }
 
 constexpr int HID = 2048;
+constexpr unsigned GRAN_TAG = 0x5EA30001u;                 // granule buffers are zeroed before every replay
 __device__ __forceinline__ auto make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
 }
@@ -89,9 +90,18 @@ __device__ __forceinline__ void resnorm_row(int m, int t, float* red, const floa
     bf16* dst = x16 + x16_index(m, 8 * t, MT);
     if constexpr (XS == 0) {
         *reinterpret_cast<bf16x8*>(dst) = xo;
-    } else {
+    } else if constexpr (XS == 1) {
         (void)dst;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo), make_rsrc(x16), (int)(x16_index(m, 8 * t, MT) * 2), 0, 16);   // aux 16 = sc1
+    } else {
+        // granules: 8 bytes = {tag, two bf16}; the fragment's four granules are 32 contiguous bytes, written by two 16-byte
+        // write-through stores (each 8-byte half lands whole); the data is its own flag
+        (void)dst;
+        const u32x4 v = __builtin_bit_cast(u32x4, xo);
+        const auto r = make_rsrc(x16);
+        const int off = (int)(x16_index(m, 8 * t, MT) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{GRAN_TAG, v[0], GRAN_TAG, v[1]}, r, off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{GRAN_TAG, v[2], GRAN_TAG, v[3]}, r, off + 16, 0, 16);
     }
 }
 
@@ -113,7 +123,7 @@ struct Seam {
 };
 #define STAMP(k) do { if (sm.stamps && threadIdx.x == 0) sm.stamps[(long)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 
-template <int TPW, int NKS, int EPI, int WAVES, int SS, bool FUSED>
+template <int TPW, int NKS, int EPI, int WAVES, int SS, int FUSED>
 __global__ __launch_bounds__(64 * WAVES) void sk4_kernel(const bf16* X16, const bf16* __restrict__ Wt, int M, int N, int K, float* __restrict__ slab,
                                                          bf16* __restrict__ out, int gx, const Seam sm) {
     constexpr int MT = 2;
@@ -127,6 +137,11 @@ __global__ __launch_bounds__(64 * WAVES) void sk4_kernel(const bf16* X16, const 
             const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
             const int m = min(bid * RPW + grp, sm.rows - 1);   // a surplus group repeats the last row (same bytes twice)
             STAMP(0);
+            if constexpr (FUSED == 2) {
+                resnorm_row<SS, 2>(m, t, red + 4 * grp, sm.slab, sm.slab_stride, sm.h_in, sm.h_out, sm.w, const_cast<bf16*>(X16), MT, sm.eps, true);
+                STAMP(1);
+                return;                                        // no drain, no counter: the granules carry their own tags
+            }
             resnorm_row<SS, 1>(m, t, red + 4 * grp, sm.slab, sm.slab_stride, sm.h_in, sm.h_out, sm.w, const_cast<bf16*>(X16), MT, sm.eps, true);
             STAMP(1);                                          // row arithmetic done, stores issued
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
@@ -160,7 +175,44 @@ __global__ __launch_bounds__(64 * WAVES) void sk4_kernel(const bf16* X16, const 
 #pragma unroll
         for (int t = 0; t < TPW; ++t) w16[i][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ((long)t * (K >> 5) + i) * 512));
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (FUSED) {
+    if constexpr (FUSED == 2) {
+        // every wave sweeps its own fragments' granules until all tags are this launch's (bounded)
+        const auto xr = make_rsrc(X16);
+        u32x4 ga[NKS][MT], gb[NKS][MT];
+        unsigned spins = 0;
+        if (sm.stamps && threadIdx.x == 0) { (void)__hip_atomic_load(sm.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(1); }
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < NKS; ++i)
+#pragma unroll
+                for (int mc = 0; mc < MT; ++mc) {
+                    const int off = (int)((((long)(ks0 + i) * MT + mc) * 512 + lane * 8) * 4);
+                    ga[i][mc] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 16);
+                    gb[i][mc] = __builtin_amdgcn_raw_buffer_load_b128(xr, off + 16, 0, 16);
+                }
+#pragma unroll
+            for (int i = 0; i < NKS; ++i)
+#pragma unroll
+                for (int mc = 0; mc < MT; ++mc)
+                    ok = ok && ga[i][mc][0] == GRAN_TAG && ga[i][mc][2] == GRAN_TAG && gb[i][mc][0] == GRAN_TAG && gb[i][mc][2] == GRAN_TAG;
+            // rows >= M are never published: their lanes' granules stay zero; only rows < M count
+            const int li_ = lane & 15;
+            bool need = true;
+            (void)li_;
+            if (__all(ok || !need)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 2000000u) { if (lane == 0) __hip_atomic_store(sm.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        STAMP(2);
+#pragma unroll
+        for (int i = 0; i < NKS; ++i)
+#pragma unroll
+            for (int mc = 0; mc < MT; ++mc) xf[i][mc] = __builtin_bit_cast(bf16x8, u32x4{ga[i][mc][1], ga[i][mc][3], gb[i][mc][1], gb[i][mc][3]});
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(3);
+    }
+    if constexpr (FUSED == 1) {
         const int NP = (sm.rows + RPW - 1) / RPW;
         if (threadIdx.x == 0) {
             unsigned spins = 0;
@@ -236,10 +288,10 @@ __global__ __launch_bounds__(64 * WAVES) void sk4_kernel(const bf16* X16, const 
 static hipStream_t st;
 static int M_ = 32;
 
-template <int TPW, int NKS, int EPI, int WAVES, int SS, bool FUSED>
+template <int TPW, int NKS, int EPI, int WAVES, int SS, int FUSED>
 static void launch_sk4(const bf16* X, const bf16* W, int N, int K, float* slab, bf16* out, const Seam& sm) {
     const int gx = N / 16 / TPW, S = K / (32 * NKS * WAVES);
-    const int NP = FUSED ? (M_ + WAVES / 4 - 1) / (WAVES / 4) : 0;
+    const int NP = FUSED != 0 ? (M_ + WAVES / 4 - 1) / (WAVES / 4) : 0;
     const size_t lds = (size_t)WAVES * TPW * 2 * 64 * 16;
     static bool attr = false;
     if (!attr) { CK(hipFuncSetAttribute((const void*)sk4_kernel<TPW, NKS, EPI, WAVES, SS, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
@@ -270,10 +322,14 @@ int main(int argc, char** argv) {
     bf16* w1 = alloc_fill(HID, 8u, 1.0f);
     bf16* w2 = alloc_fill(HID, 9u, 1.0f);
     bf16* h0 = alloc_fill((size_t)32 * HID, 10u, 1.0f);
-    bf16 *h[2], *xa[2], *xb[2], *act[2];
-    float *slabA[2], *slabB[2], *slabQ[2];
+    bf16 *h[3], *xa[3], *xb[3], *act[3];
+    float *slabA[3], *slabB[3], *slabQ[3];
     unsigned *cnt, *fail;
-    for (int a = 0; a < 2; ++a) {
+    // arm C: one granule image (twice the X16 bytes) per seam of every layer, zeroed before every replay
+    const size_t gran_bytes = (size_t)MT * 16 * HID * 4;
+    char* gran;
+    CK(hipMalloc(&gran, gran_bytes * 2 * L));
+    for (int a = 0; a < 3; ++a) {
         CK(hipMalloc(&h[a], (size_t)32 * HID * 2));
         CK(hipMalloc(&xa[a], (size_t)MT * 16 * HID * 2)); CK(hipMalloc(&xb[a], (size_t)MT * 16 * HID * 2));
         CK(hipMalloc(&act[a], (size_t)MT * 16 * I * 2));
@@ -293,37 +349,40 @@ int main(int argc, char** argv) {
     auto layer = [&](int arm, int l) {
         Seam none{};
         // o: att16 -> slabA (4 slabs)
-        launch_sk4<2, 2, 0, 8, 4, false>(att16, Wo[l], HID, HID, slabA[arm], nullptr, none);
+        launch_sk4<2, 2, 0, 8, 4, 0>(att16, Wo[l], HID, HID, slabA[arm], nullptr, none);
         if (arm == 0) {
             hipLaunchKernelGGL(resnorm_kernel<4>, dim3(M_), dim3(256), 0, st, slabA[arm], (long)32 * HID, h[arm], h[arm], w1, xa[arm], MT, 1e-6f);
-            launch_sk4<4, 4, 2, 16, 4, false>(xa[arm], Wgu[l], 2 * I, HID, nullptr, act[arm], none);
+            launch_sk4<4, 4, 2, 16, 4, 0>(xa[arm], Wgu[l], 2 * I, HID, nullptr, act[arm], none);
         } else {
             Seam s{slabA[arm], (long)32 * HID, h[arm], h[arm], w1, 1e-6f, cnt + 2 * l, fail, M_, delay_gu, stamp_layer == l ? stampA : nullptr};
-            launch_sk4<4, 4, 2, 16, 4, true>(xa[arm], Wgu[l], 2 * I, HID, nullptr, act[arm], s);
+            if (arm == 1) launch_sk4<4, 4, 2, 16, 4, 1>(xa[arm], Wgu[l], 2 * I, HID, nullptr, act[arm], s);
+            else launch_sk4<4, 4, 2, 16, 4, 2>((const bf16*)(gran + gran_bytes * (2 * l)), Wgu[l], 2 * I, HID, nullptr, act[arm], s);
         }
-        launch_sk4<2, 3, 0, 16, 4, false>(act[arm], Wdn[l], HID, I, slabB[arm], nullptr, none);
+        launch_sk4<2, 3, 0, 16, 4, 0>(act[arm], Wdn[l], HID, I, slabB[arm], nullptr, none);
         if (arm == 0) {
             hipLaunchKernelGGL(resnorm_kernel<4>, dim3(M_), dim3(256), 0, st, slabB[arm], (long)32 * HID, h[arm], h[arm], w2, xb[arm], MT, 1e-6f);
-            launch_sk4<2, 4, 0, 8, 4, false>(xb[arm], Wqkv[l], NQKV, HID, slabQ[arm], nullptr, none);
+            launch_sk4<2, 4, 0, 8, 4, 0>(xb[arm], Wqkv[l], NQKV, HID, slabQ[arm], nullptr, none);
         } else {
             Seam s{slabB[arm], (long)32 * HID, h[arm], h[arm], w2, 1e-6f, cnt + 2 * l + 1, fail, M_, delay_qkv, stamp_layer == l ? stampB : nullptr};
-            launch_sk4<2, 4, 0, 8, 4, true>(xb[arm], Wqkv[l], NQKV, HID, slabQ[arm], nullptr, s);
+            if (arm == 1) launch_sk4<2, 4, 0, 8, 4, 1>(xb[arm], Wqkv[l], NQKV, HID, slabQ[arm], nullptr, s);
+            else launch_sk4<2, 4, 0, 8, 4, 2>((const bf16*)(gran + gran_bytes * (2 * l + 1)), Wqkv[l], NQKV, HID, slabQ[arm], nullptr, s);
         }
     };
-    hipGraphExec_t ge[2];
-    for (int arm = 0; arm < 2; ++arm) {
+    hipGraphExec_t ge[3];
+    for (int arm = 0; arm < 3; ++arm) {
         hipGraph_t g;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         CK(hipMemcpyAsync(h[arm], h0, (size_t)32 * HID * 2, hipMemcpyDeviceToDevice, st));
         if (arm == 1) CK(hipMemsetAsync(cnt, 0, cnt_bytes, st));
+        if (arm == 2) CK(hipMemsetAsync(gran, 0, gran_bytes * 2 * L, st));
         for (int l = 0; l < L; ++l) layer(arm, l);
         CK(hipStreamEndCapture(st, &g));
         CK(hipGraphInstantiate(&ge[arm], g, nullptr, nullptr, 0));
         CK(hipGraphDestroy(g));
     }
-    std::vector<float> ts[2];
+    std::vector<float> ts[3];
     for (int r = 0; r < rounds; ++r)
-        for (int arm = 0; arm < 2; ++arm) {
+        for (int arm = 0; arm < 3; ++arm) {
             CK(hipEventRecord(e0, st));
             CK(hipGraphLaunch(ge[arm], st));
             CK(hipEventRecord(e1, st));
@@ -334,31 +393,33 @@ int main(int argc, char** argv) {
     // equality of the two arms: residual stream, last X images, last qkv slabs
     auto fetch = [&](const void* p, size_t n) { std::vector<unsigned char> v(n); CK(hipMemcpy(v.data(), p, n, hipMemcpyDeviceToHost)); return v; };
     size_t diff = 0;
-    {
-        auto a = fetch(h[0], (size_t)M_ * HID * 2), b = fetch(h[1], (size_t)M_ * HID * 2);
+    for (int other = 1; other < 3; ++other) {
+        auto a = fetch(h[0], (size_t)M_ * HID * 2), b = fetch(h[other], (size_t)M_ * HID * 2);
         for (size_t i = 0; i < a.size(); ++i) diff += a[i] != b[i];
-        auto c = fetch(slabQ[0], (size_t)2 * 32 * NQKV * 4), d = fetch(slabQ[1], (size_t)2 * 32 * NQKV * 4);
+        auto c = fetch(slabQ[0], (size_t)2 * 32 * NQKV * 4), d = fetch(slabQ[other], (size_t)2 * 32 * NQKV * 4);
         // rows >= M are never written: compare the written rows of both slabs
         for (int s = 0; s < 2; ++s)
             for (size_t i = 0; i < (size_t)M_ * NQKV * 4; ++i) diff += c[(size_t)s * M_ * NQKV * 4 + i] != d[(size_t)s * M_ * NQKV * 4 + i];
-        auto e = fetch(act[0], (size_t)MT * 16 * I * 2), f = fetch(act[1], (size_t)MT * 16 * I * 2);
+        auto e = fetch(act[0], (size_t)MT * 16 * I * 2), f = fetch(act[other], (size_t)MT * 16 * I * 2);
         if (M_ == 32) for (size_t i = 0; i < e.size(); ++i) diff += e[i] != f[i];
     }
     unsigned failed = 0;
     CK(hipMemcpy(&failed, fail, 4, hipMemcpyDeviceToHost));
-    for (int arm = 0; arm < 2; ++arm) {
+    const char* arm_name[3] = {"A separate launches (6 per layer)", "B flag hand-off (4 per layer)", "C granule hand-off (4 per layer)"};
+    for (int arm = 0; arm < 3; ++arm) {
         std::sort(ts[arm].begin(), ts[arm].end());
-        printf("arm %c (%d launches per layer): median %.2f us per layer, min %.2f, max %.2f\n", arm ? 'B' : 'A', arm ? 4 : 6, ts[arm][ts[arm].size() / 2],
-               ts[arm].front(), ts[arm].back());
+        printf("arm %-34s median %.2f us per layer, min %.2f, max %.2f\n", arm_name[arm], ts[arm][ts[arm].size() / 2], ts[arm].front(), ts[arm].back());
     }
     printf("consumer delays: gate/up %d, qkv %d (x 64 cycles)\n", delay_gu, delay_qkv);
     printf("bytes differing between the arms: %zu; spin timeouts: %u\n", diff, failed);
-    if (argc > 4 && !strcmp(argv[4], "stamp")) {             // stamp mode: one eager pass of arm B, layer L/2 instrumented
+    if (argc > 4 && !strncmp(argv[4], "stamp", 5)) {         // stamp mode: one eager pass of arm B ("stamp") or C ("stampc"), layer L/2 instrumented
+        const int sarm = !strcmp(argv[4], "stampc") ? 2 : 1;
         stamp_layer = L / 2;
         CK(hipMemset(stampA, 0, 512 * 64)); CK(hipMemset(stampB, 0, 512 * 64));
-        CK(hipMemcpyAsync(h[1], h0, (size_t)32 * HID * 2, hipMemcpyDeviceToDevice, st));
+        CK(hipMemcpyAsync(h[sarm], h0, (size_t)32 * HID * 2, hipMemcpyDeviceToDevice, st));
         CK(hipMemsetAsync(cnt, 0, cnt_bytes, st));
-        for (int l = 0; l < L; ++l) layer(1, l);
+        CK(hipMemsetAsync(gran, 0, gran_bytes * 2 * L, st));
+        for (int l = 0; l < L; ++l) layer(sarm, l);
         CK(hipStreamSynchronize(st));
         const char* names[2] = {"gate/up'", "qkv'"};
         unsigned long long* bufs[2] = {stampA, stampB};
