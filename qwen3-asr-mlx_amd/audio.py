@@ -205,11 +205,17 @@ def pack_audio(batch: Sequence[np.ndarray], device):
     if ev is not None:
         ev.synchronize()                                   # the previous request's H2D copy has read the buffer
     host = flat[:n].view(len(batch), lmax)
-    for i, a in enumerate(batch):
-        host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-        if lens[i] < lmax:
-            host[i, lens[i]:] = 0.0
-    dev = host.to(dev_t, non_blocking=True)
+    dev = torch.empty((len(batch), lmax), dtype=torch.float32, device=dev_t)
+    # rows are staged and copied in groups: the H2D copy of one group runs while the host fills the next (a 32 x 30 s
+    # request is 61 MB: ~2 ms of host copy + ~1 ms over PCIe one after the other)
+    group = max(1, (8 << 20) // max(4 * lmax, 1))
+    for i0 in range(0, len(batch), group):
+        i1 = min(i0 + group, len(batch))
+        for i in range(i0, i1):
+            host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(batch[i], dtype=np.float32))
+            if lens[i] < lmax:
+                host[i, lens[i]:] = 0.0
+        dev[i0:i1].copy_(host[i0:i1], non_blocking=True)
     lens_dev = torch.tensor(lens, dtype=torch.int32).to(dev_t, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev.device))
