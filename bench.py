@@ -132,7 +132,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the batches-in-flight throughput leg")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight in the throughput leg (host threads / lanes)")
+    ap.add_argument("--inflight", type=str, default="2,4", help="batches in flight in the throughput legs (host threads / lanes), comma-separated")
     ap.add_argument("--weights", choices=("bf16", "fp8", "fp8w"), default="bf16",
                     help="fp8: decoder weights quantised on load, prefill on the fp8 MFMA (BASELINE.json configs[4]; not the headline "
                          "config); fp8w: weight-only variant")
@@ -372,48 +372,49 @@ def main() -> None:
         # that keeps the GPU fed, with the per-batch latency it costs.
         import threading
         from qwen3_asr_mlx_amd.decoder import set_lane
-        n_each, lat2, errs = 8, [], []                 # per lane: enough batches that the ramp at both ends stays small
-        gate = threading.Barrier(args.inflight + 1)
+        for n_lanes in [int(v) for v in str(args.inflight).split(",") if v.strip()]:
+            n_each, lat2, errs = 8, [], []                 # per lane: enough batches that the ramp at both ends stays small
+            gate = threading.Barrier(n_lanes + 1)
 
-        def worker(lane):
-            try:
-                set_lane(lane)
-                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                    model.generate_tokens_device(audio, lens_dev, lens, budgets, "English", repetition_penalty=1.2)   # lane warm-up
-                    torch.cuda.current_stream().synchronize()
-                    gate.wait()
-                    for _ in range(n_each):
-                        s0 = time.perf_counter()
-                        t_ = model.generate_tokens_device(audio, lens_dev, lens, budgets, "English", repetition_penalty=1.2)
+            def worker(lane):
+                try:
+                    set_lane(lane)
+                    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                        model.generate_tokens_device(audio, lens_dev, lens, budgets, "English", repetition_penalty=1.2)   # lane warm-up
                         torch.cuda.current_stream().synchronize()
-                        lat2.append(time.perf_counter() - s0)
-                        assert all(len(x) == args.ndec for x in t_)
-                    gate.wait()
-            except Exception as e:                                       # noqa: BLE001
-                errs.append(repr(e))
-                gate.abort()
+                        gate.wait()
+                        for _ in range(n_each):
+                            s0 = time.perf_counter()
+                            t_ = model.generate_tokens_device(audio, lens_dev, lens, budgets, "English", repetition_penalty=1.2)
+                            torch.cuda.current_stream().synchronize()
+                            lat2.append(time.perf_counter() - s0)
+                            assert all(len(x) == args.ndec for x in t_)
+                        gate.wait()
+                except Exception as e:                                       # noqa: BLE001
+                    errs.append(repr(e))
+                    gate.abort()
 
-        ths = [threading.Thread(target=worker, args=(lane,)) for lane in range(1, args.inflight + 1)]
-        for th in ths:
-            th.start()
-        try:
-            gate.wait()
-            p0 = time.perf_counter()
-            gate.wait()
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - p0
-        except threading.BrokenBarrierError:
-            dt2 = None
-        for th in ths:
-            th.join()
-        if dt2 is not None and not errs:
-            key = "two_in_flight" if args.inflight == 2 else f"in_flight_{args.inflight}"
-            line[key] = {"value": args.inflight * n_each * B * args.clip_seconds / dt2, "unit": "audio-s/wall-s",
-                         "batches": args.inflight * n_each, "p50_latency_ms": 1e3 * float(np.median(lat2)),
-                         "note": f"same batch-{B} requests, {args.inflight} in flight on their own lanes/streams; `value` above is one at a time"}
-            log(f"{args.inflight} batches in flight: RTF {line[key]['value']:.0f}x, per-batch latency p50 {line[key]['p50_latency_ms']:.0f} ms")
-        else:
-            log(f"two-in-flight leg failed: {errs}")
+            ths = [threading.Thread(target=worker, args=(lane,)) for lane in range(1, n_lanes + 1)]
+            for th in ths:
+                th.start()
+            try:
+                gate.wait()
+                p0 = time.perf_counter()
+                gate.wait()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - p0
+            except threading.BrokenBarrierError:
+                dt2 = None
+            for th in ths:
+                th.join()
+            if dt2 is not None and not errs:
+                key = "two_in_flight" if n_lanes == 2 else f"in_flight_{n_lanes}"
+                line[key] = {"value": n_lanes * n_each * B * args.clip_seconds / dt2, "unit": "audio-s/wall-s",
+                             "batches": n_lanes * n_each, "p50_latency_ms": 1e3 * float(np.median(lat2)),
+                             "note": f"same batch-{B} requests, {n_lanes} in flight on their own lanes/streams; `value` above is one at a time"}
+                log(f"{n_lanes} batches in flight: RTF {line[key]['value']:.0f}x, per-batch latency p50 {line[key]['p50_latency_ms']:.0f} ms")
+            else:
+                log(f"{n_lanes}-in-flight leg failed: {errs}")
     if world == 1:
         # ---- per-stage time of one step against each stage's own roofline (SURVEY.md section 8d work figures)
         from qwen3_asr_mlx_amd.generate import _merge, _side_stream
