@@ -20,12 +20,15 @@
 #define KV_TILE 64
 
 template <int HD> struct TileImg;
-// 256-byte rows: 16-byte chunk ch of row r sits at 256 r + 16 (ch ^ f(r)); conflict-free for row reads
-// and transposed reads (cdna_hip_programming.md T10 image (b)).
+// 256-byte rows: 16-byte chunk ch of row r sits at 256 r + 16 (ch ^ f(r)), f(r) = (r & 7) << 1.  Round 4: the f of rounds 1-3,
+// ((r & 3) << 2) | ((r >> 2) & 3), was 2-way conflicted on both read patterns -- in a ds_read_b128 lane group (lanes 0-3, 12-15,
+// 20-27: rows li = 0-3 and 12-15 at chunk 4 ks, rows 4-11 at chunk 4 ks + 1) rows 4-7 landed on the slots of rows 0-3, and in
+// a ds_read_b64_tr_b16 half-wave (8 rows x chunks 2 dt, 2 dt + 1) rows r and r + 4 swapped slots: SQ_LDS_BANK_CONFLICT was
+// 39 % of SQ_LDS_IDX_ACTIVE in the prefill attention (tools/pmc_attn.sh).  This f is conflict-free for the K row reads, the
+// transposing V reads and the staging writes under the bank model of MI355X_MICROARCH.md (64 banks x 4 B; lane groups per
+// instruction), found by exhaustive search over the XOR-linear f (results are unchanged: a layout, not arithmetic).
 template <> struct TileImg<128> {
-    static __device__ __forceinline__ int off(int row, int ch) {
-        return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-    }
+    static __device__ __forceinline__ int off(int row, int ch) { return 256 * row + 16 * (ch ^ ((row & 7) << 1)); }
 };
 template <> struct TileImg<64> {
     static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ (row & 7)); }

@@ -782,7 +782,7 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, vo
 
 // 256-byte rows of a V tile in LDS: 16-byte chunk ch of row r sits at 256 r + 16 (ch ^ f(r)); conflict-free for the row
 // writes and for the transposing reads (same image as the prefill kernel, attn.hip)
-__device__ __forceinline__ int adm_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ int adm_off(int row, int ch) { return 256 * row + 16 * (ch ^ ((row & 7) << 1)); }   // round 4: conflict-free (attn.hip, TileImg<128>)
 
 // NT: the cached keys / values are read with non-temporal loads (a cache that is streamed once per step).
 template <bool NT>
