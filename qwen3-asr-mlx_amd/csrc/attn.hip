@@ -27,10 +27,13 @@ template <int HD> struct TileImg;
 // 39 % of SQ_LDS_IDX_ACTIVE in the prefill attention (tools/pmc_attn.sh).  This f is conflict-free for the K row reads, the
 // transposing V reads and the staging writes under the bank model of MI355X_MICROARCH.md (64 banks x 4 B; lane groups per
 // instruction), found by exhaustive search over the XOR-linear f (results are unchanged: a layout, not arithmetic).
+// Both images depend on the row only through row & 7: off(row + 8 j, ch) = off(row, ch) + 8 j ROWB.
 template <> struct TileImg<128> {
+    static constexpr int ROWB = 256;
     static __device__ __forceinline__ int off(int row, int ch) { return 256 * row + 16 * (ch ^ ((row & 7) << 1)); }
 };
 template <> struct TileImg<64> {
+    static constexpr int ROWB = 128;
     static __device__ __forceinline__ int off(int row, int ch) { return 128 * row + 16 * (ch ^ (row & 7)); }
 };
 
@@ -87,52 +90,87 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NCH = KV_TILE * CPR / 256;
     u32x4 kreg[NCH], vreg[NCH];
+    // a key row's byte offset from the (uniform) tile base as ONE 32-bit value shared by the K and the V load (host-checked
+    // to fit): ~3 VALU per row instead of the ~9 of two 64-bit address chains -- the loop is VALU-issue-bound once the LDS
+    // round trips are grouped (round 4, tools/pmc_attn.sh)
+    const unsigned row_bytes = (unsigned)p.kv_row_stride * 2u, ch_bytes = (unsigned)(tid % CPR) * 16u;
+    const int row0 = tid / CPR;
     auto fetch = [&](int kt_) {
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {
-            const int c = tid + 256 * it;
-            const int row = c / CPR, ch = c - row * CPR;
-            const int key = min(kt_ * KV_TILE + row, len - 1);
-            kreg[it] = *reinterpret_cast<const u32x4*>(Kb + (long)key * p.kv_row_stride + ch * 8);
-            vreg[it] = *reinterpret_cast<const u32x4*>(Vb + (long)key * p.kv_row_stride + ch * 8);
+            const int key = min(kt_ * KV_TILE + row0 + (256 / CPR) * it, len - 1);
+            const unsigned boff = (unsigned)key * row_bytes + ch_bytes;
+            kreg[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Kb) + boff);
+            vreg[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Vb) + boff);
         }
     };
+    static_assert((256 / CPR) % 8 == 0, "staging rows of one thread must be a multiple of 8 apart");
+    const int wbase = TileImg<HD>::off(row0, tid % CPR);
+    // fragment read bases: the k-step / d-tile index enters the swizzled chunk by XOR (bits above the row term), so one base
+    // each and an XOR per read replace 4 + 8 address registers
+    const int kbase = TileImg<HD>::off(li, g);
+    const int vbase = TileImg<HD>::off(4 * g + (li >> 2), (li & 3) >> 1) + 8 * (li & 1);
     fetch(0);
+    int last_tile = n_tiles - 1;
+    asm volatile("" : "+s"(last_tile));                  // opaque: hipcc otherwise peels the masked tile out of the loop and spills at the join
     for (int kt = 0; kt < n_tiles; ++kt) {
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < NCH; ++it) {
-            const int c = tid + 256 * it;
-            const int row = c / CPR, ch = c - row * CPR;
-            *reinterpret_cast<u32x4*>(sK + TileImg<HD>::off(row, ch)) = kreg[it];
-            *reinterpret_cast<u32x4*>(sV + TileImg<HD>::off(row, ch)) = vreg[it];
+        for (int it = 0; it < NCH; ++it) {                  // rows row0 + (256 / CPR) it: a multiple of 8 apart, one base (ROWB note)
+            *reinterpret_cast<u32x4*>(sK + wbase + it * (256 / CPR) * TileImg<HD>::ROWB) = kreg[it];
+            *reinterpret_cast<u32x4*>(sV + wbase + it * (256 / CPR) * TileImg<HD>::ROWB) = vreg[it];
         }
         if (kt + 1 < n_tiles) fetch(kt + 1);
         __syncthreads();
 
-        // ---- S^T = K Q^T
+        // ---- S^T = K Q^T.  Round 4: k-step outer, the four key tiles' fragments read as one group in front of their four
+        // MFMAs.  Written key-tile outer, hipcc (at the 170-VGPR cap of three workgroups per CU) emitted ds_read ->
+        // s_waitcnt lgkmcnt(0) -> MFMA sixteen times in a row, the four MFMAs of a key tile back to back on ONE accumulator:
+        // 32 exposed LDS round trips and 12 dependent-MFMA stalls per key tile and wave (with PV below), which is what the
+        // stamps of round 3 called "latency-bound".  Each accumulator still sees its k-steps in ascending order: same bits.
         f32x4 s[4];
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            s[k4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k4 = 0; k4 < 4; ++k4) s[k4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[2][4];                                     // the next k-step's fragments are requested before this one's MFMAs
+        auto read_k = [&](int ks, bf16x8 (&f)[4]) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + TileImg<HD>::off(16 * k4 + li, 4 * ks + g));
-                s[k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[k4], 0, 0, 0);
-            }
+            for (int k4 = 0; k4 < 4; ++k4)                   // off(16 k4 + li, 4 ks + g) = (off(li, g) ^ (ks << 6)) + 16 k4 ROWB
+                f[k4] = *reinterpret_cast<const bf16x8*>(sK + ((kbase ^ (ks << 6)) + 16 * k4 * TileImg<HD>::ROWB));
+        };
+        read_k(0, kf[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) read_k(ks + 1, kf[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) s[k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][k4], qf[ks], s[k4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- mask + online softmax (row = query li, spread over the 4 lane groups)
+        // Only the last key tile of a query tile can hold keys beyond the sequence or above the diagonal (earlier tiles end
+        // below key 64 qt <= every query row of the workgroup, and 64 qt < len): the mask runs there alone (uniform branch).
         float tmax = -INFINITY;
+        if (kt == last_tile) {
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
+            for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * KV_TILE + 16 * k4 + 4 * g + r;
-                const bool ok = key < len && (!CAUSAL || key <= q_eff);
-                const float v = ok ? s[k4][r] * p.scale : -INFINITY;
-                s[k4][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * KV_TILE + 16 * k4 + 4 * g + r;
+                    const bool ok = key < len && (!CAUSAL || key <= q_eff);
+                    const float v = ok ? s[k4][r] * p.scale : -INFINITY;
+                    s[k4][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = s[k4][r] * p.scale;
+                    s[k4][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+        }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);          // finite: key 0 is visible to every query
@@ -149,38 +187,55 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
         // ---- O^T += V^T P^T
-        const int q4 = li >> 2, p4 = li & 3;
+        // the transposing V reads of four d tiles as one group in front of their four MFMAs (independent accumulators), as above
+        // group q = (key half c, four d tiles d0): rows 32 c + 4 g + (li >> 2) and + 16 (immediate row steps, ROWB note above),
+        // chunk 2 dt + ((li & 3) >> 1): the d tile enters the swizzled chunk by XOR above bit 4; the next group's reads are
+        // requested before this group's MFMAs
+        union VFrag { struct { s16x4 a, b; } h; bf16x8 v; };
+        constexpr int NG = 2 * (DT / 4);
+        VFrag u[2][4];
+        auto read_v = [&](int q, VFrag (&f)[4]) {
+            const int c = q / (DT / 4), d0 = 4 * (q % (DT / 4));
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int ch = 2 * dt + (p4 >> 1);
-                const int r_lo = 32 * c + 4 * g + q4;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(sV + TileImg<HD>::off(r_lo, ch) + 8 * (p4 & 1)));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(sV + TileImg<HD>::off(r_lo + 16, ch) + 8 * (p4 & 1)));
-                union { struct { s16x4 a, b; } h; bf16x8 v; } u;
-                u.h.a = lo;
-                u.h.b = hi;
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[c], o[dt], 0, 0, 0);
+            for (int dd = 0; dd < 4; ++dd) {
+                const int vb = vbase ^ ((d0 + dd) << 5);
+                f[dd].h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sV + vb + (32 * c) * TileImg<HD>::ROWB));
+                f[dd].h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sV + vb + (32 * c + 16) * TileImg<HD>::ROWB));
             }
+        };
+        read_v(0, u[0]);
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            if (q + 1 < NG) read_v(q + 1, u[(q + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int c = q / (DT / 4), d0 = 4 * (q % (DT / 4));
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) o[d0 + dd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[q & 1][dd].v, pf[c], o[d0 + dd], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
-    if (q_abs < len) {
+    // the output addresses are rebuilt here from an opaque copy of the thread id: hoisted above the key loop they stayed live
+    // across it, and at the 168-register cap of three workgroups per CU that cost spills
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int q_abs2 = qt * 64 + (tid2 >> 6) * 16 + (tid2 & 15), g2 = (tid2 & 63) >> 4;
+    if (q_abs2 < len) {
         const float inv = 1.0f / l_tot;
-        bf16* orow = p.O + ((long)p.seg_q_start[seg] + q_abs) * p.o_stride + head * HD;
+        bf16* orow = p.O + ((long)p.seg_q_start[seg] + q_abs2) * p.o_stride + head * HD;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             bf16x4 ov;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ov[r] = f2bf(o[dt][r] * inv);
-            *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g) = ov;
+            *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g2) = ov;
         }
     }
 }
@@ -192,6 +247,7 @@ extern "C" int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, co
     Q3_REQUIRE(Q && K && V && kv_seg_off && O && seg_q_start && seg_len, "attn_fwd: null pointer");
     Q3_REQUIRE(n_segs > 0 && max_len > 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "attn_fwd: bad sizes");
     Q3_REQUIRE(q_stride % 8 == 0 && kv_row_stride % 8 == 0 && kv_head_stride % 8 == 0 && o_stride % 4 == 0, "attn_fwd: strides must keep 16-byte alignment");
+    Q3_REQUIRE(kv_row_stride > 0 && (int64_t)max_len * kv_row_stride * 2 < (1LL << 32), "attn_fwd: a segment's K/V rows must lie within 4 GiB of its first (max_len=%d, kv_row_stride=%ld)", max_len, (long)kv_row_stride);
     AttnParams p;
     p.Q = (const bf16*)Q; p.q_stride = q_stride; p.K = (const bf16*)K; p.V = (const bf16*)V;
     p.kv_seg_off = (const long*)kv_seg_off; p.kv_head_stride = kv_head_stride; p.kv_row_stride = kv_row_stride;

@@ -945,17 +945,20 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                 }                                                                                               \
             l_run = l_run * alpha_ + psum_;                                                                     \
             m_run = m_new_;                                                                                     \
-            _Pragma("unroll") for (int dt = 0; dt < 8; ++dt) {                                                  \
-                o_[dt] *= alpha_;                                                                               \
-                const int ch_ = 2 * dt + (p4 >> 1), r_lo_ = 4 * g + q4;                                         \
-                const s16x4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                      \
-                    (s16x4 __attribute__((address_space(3)))*)(sVw + adm_off(r_lo_, ch_) + 8 * (p4 & 1)));      \
-                const s16x4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                      \
-                    (s16x4 __attribute__((address_space(3)))*)(sVw + adm_off(r_lo_ + 16, ch_) + 8 * (p4 & 1))); \
-                union { struct { s16x4 a, b; } h; bf16x8 v; } u_;                                               \
-                u_.h.a = lo_;                                                                                   \
-                u_.h.b = hi_;                                                                                   \
-                o_[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_.v, pf_, o_[dt], 0, 0, 0);                   \
+            /* round 4: the transposing V reads of four d tiles as one group in front of their four MFMAs (independent    \
+               accumulators) -- read, wait, MFMA one d tile at a time exposed eight LDS round trips per key tile (attn.hip) */ \
+            _Pragma("unroll") for (int d0_ = 0; d0_ < 8; d0_ += 4) {                                            \
+                union { struct { s16x4 a, b; } h; bf16x8 v; } u_[4];                                            \
+                _Pragma("unroll") for (int dd_ = 0; dd_ < 4; ++dd_) {                                           \
+                    const int vb_ = adm_off(4 * g + q4, 2 * (d0_ + dd_) + (p4 >> 1)) + 8 * (p4 & 1);            \
+                    u_[dd_].h.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sVw + vb_));          \
+                    u_[dd_].h.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sVw + vb_ + 16 * 256)); \
+                }                                                                                               \
+                _Pragma("unroll") for (int dd_ = 0; dd_ < 4; ++dd_) o_[d0_ + dd_] *= alpha_;                    \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
+                _Pragma("unroll") for (int dd_ = 0; dd_ < 4; ++dd_)                                             \
+                    o_[d0_ + dd_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u_[dd_].v, pf_, o_[d0_ + dd_], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                              \
             }                                                                                                   \
         }
         const int t_endm = min(L, c_end * ADF_CHUNK);
