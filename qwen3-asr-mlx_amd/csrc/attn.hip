@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
                     tmax = fmaxf(tmax, v);
                 }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = lane_xor16_max(tmax);                     // = fmaxf(tmax, tmax[lane ^ 16]) without the LDS crossbar (common.h)
+        tmax = lane_xor32_max(tmax);
         const float m_new = fmaxf(m_run, tmax);          // finite: key 0 is visible to every query
         const float alpha = __expf(m_run - m_new);       // m_run = -inf on the first tile -> 0
         float psum = 0.f;
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
+    float l_tot = lane_xor16_sum(l_run);
+    l_tot = lane_xor32_sum(l_tot);
     // the output addresses are rebuilt here from an opaque copy of the thread id: hoisted above the key loop they stayed live
     // across it, and at the 168-register cap of three workgroups per CU that cost spills
     int tid2 = threadIdx.x;

@@ -58,14 +58,46 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // ---- wave reductions (wave = 64 lanes) -----------------------------------
+// The butterfly v = op(v, v[lane ^ o]), o = 32, 16, 8, 4, 2, 1, of rounds 1-3 -- the same partners in the same order, so the
+// same bits for the commutative ops used here -- without the LDS crossbar: hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS
+// instruction and an s_waitcnt per step: ~600 cycles for a 6-step reduction on the dependent chain of every norm and
+// attention prologue).  gfx950 has v_permlane32_swap / v_permlane16_swap (row exchanges: with both operands the same
+// value, result 0 (op) result 1 = op(v, v[lane ^ 32]) resp. v[lane ^ 16] in every lane) and DPP covers the steps inside a
+// row of 16: row_ror:8 = lane ^ 8, row_half_mirror then quad_perm [3,2,1,0] = lane ^ 7 ^ 3 = lane ^ 4, quad_perm [2,3,0,1]
+// = lane ^ 2, [1,0,3,2] = lane ^ 1.  Round 4.
+#define Q3_DPP(x, ctrl) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), (ctrl), 0xf, 0xf, false))
+__device__ __forceinline__ float lane_xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float lane_xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float lane_xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float lane_xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = lane_xor32_sum(v);
+    v = lane_xor16_sum(v);
+    v += Q3_DPP(v, 0x128);                                  // row_ror:8
+    v += Q3_DPP(Q3_DPP(v, 0x141), 0x1b);                    // row_half_mirror, quad_perm [3,2,1,0]
+    v += Q3_DPP(v, 0x4e);                                   // quad_perm [2,3,0,1]
+    v += Q3_DPP(v, 0xb1);                                   // quad_perm [1,0,3,2]
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = lane_xor32_max(v);
+    v = lane_xor16_max(v);
+    v = fmaxf(v, Q3_DPP(v, 0x128));
+    v = fmaxf(v, Q3_DPP(Q3_DPP(v, 0x141), 0x1b));
+    v = fmaxf(v, Q3_DPP(v, 0x4e));
+    v = fmaxf(v, Q3_DPP(v, 0xb1));
     return v;
 }
 

@@ -931,8 +931,8 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                     sc_[k4][r] = v_;                                                                            \
                     tmax_ = fmaxf(tmax_, v_);                                                                   \
                 }                                                                                               \
-            tmax_ = fmaxf(tmax_, __shfl_xor(tmax_, 16, 64));                                                    \
-            tmax_ = fmaxf(tmax_, __shfl_xor(tmax_, 32, 64));                                                    \
+            tmax_ = lane_xor16_max(tmax_);                                                                      \
+            tmax_ = lane_xor32_max(tmax_);                                                                      \
             const float m_new_ = fmaxf(m_run, tmax_);          /* finite: key TB <= pos is in every tile */      \
             const float alpha_ = __expf(m_run - m_new_);                                                        \
             float psum_ = 0.f;                                                                                  \
@@ -978,8 +978,8 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                 if (tb + 256 < ce) { ADM_LOAD(kR, vR, tb + 256) }
                 ADM_SOFTMAX_PV(tb)
             }
-            float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-            l_tot += __shfl_xor(l_tot, 32, 64);
+            float l_tot = lane_xor16_sum(l_run);
+            l_tot = lane_xor32_sum(l_tot);
             if (li < 2) {
                 if (g == 0) { s_m[wave][li] = m_run; s_l[wave][li] = l_tot; }
 #pragma unroll
