@@ -65,6 +65,8 @@ int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int 
 /* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 64 = 64x64 tile, 128 = 128x128 tile, 8 = 256x256 8-phase LDS-DMA
  * pipeline where its preconditions hold, 224 = the same pipeline on 224x256 tiles).  All kernels give bit-identical results. */
 int q3asr_gemm_force_kernel(int mode);
+/* Diagnostic: 0 = every sub-tile of the 8-phase kernels takes the general (bounds-tested) epilogue, 1 = interior sub-tiles take the short one (default). Same bits either way; returns the previous setting. Used by tools/ab_gemm_epilogue.py */
+int q3asr_gemm_set_interior(int on);
 /* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
 int q3asr_gemm_set_stamp(void* buf);
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // (read as whole rows too) after it; arithmetic and rounding points are those of gemm_epilogue, so results are bit-identical.
 // Preconditions (checked on the host, else gemm_epilogue): N % 8 == 0, ldo / ldres multiples of 8, 16-byte aligned bases.
 // ---------------------------------------------------------------------------
-template <int MI = 8>   // 16-row blocks per wave: 8 (128 rows) or 7 (the 224-row tile's 112)
+template <int MI = 8, bool INTERIOR = true>   // MI: 16-row blocks per wave, 8 (128 rows) or 7 (the 224-row tile's 112); INTERIOR: compile the interior-tile path
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n_base, int n0, int wn,
                                                   char* st, int lane) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -127,6 +127,28 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     if (p.act == 2) {                                                     // SwiGLU: 16 rows x 32 output columns per block (64-byte rows)
         const int n_out0 = (n0 >> 1) + wn * 32;
         const int rr = lane >> 2, rc = lane & 3;
+        if (INTERIOR && p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map) {   // interior sub-tile: see the bf16 path below
+            const unsigned voff = (unsigned)rr * (unsigned)p.ldo + (unsigned)(n_out0 + 8 * rc);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                char* blk = st + (i & 1) * 2048;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gt = round_bf(acc[2 * jj][i][r]);
+                        const float up = round_bf(acc[2 * jj + 1][i][r]);
+                        o[r] = f2bf(gt / (1.0f + __expf(-gt)) * up);
+                    }
+                    const int chunk = 2 * jj + (g >> 1);
+                    *reinterpret_cast<bf16x4*>(blk + li * 64 + ((chunk ^ ((li >> 1) & 3)) << 4) + (g & 1) * 8) = o;
+                }
+                const u32x4 v = *reinterpret_cast<const u32x4*>(blk + rr * 64 + ((rc ^ ((rr >> 1) & 3)) << 4));
+                *reinterpret_cast<u32x4*>((bf16*)p.out + (long)(m_base + i * 16) * p.ldo + voff) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             char* blk = st + (i & 1) * 2048;
@@ -155,6 +177,48 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     if (p.out_kind == 0) {                                                // bf16 out: 16 rows x 64 columns per block (128-byte rows)
         const int rc = lane & 7;
         const int n = n_base + 8 * rc;
+        // Round 4: a wave's sub-tile that lies wholly inside the matrix (every tile but those of the last row / column of tiles)
+        // and has no row map stores through a uniform row pointer + one 32-bit lane offset, without per-row bound tests and
+        // 64-bit address chains: a wave64 VALU instruction takes ~4 cycles on this part (tools/pmc_kernel.sh), and the general
+        // path spends a few hundred of them per tile on addresses.  Same values, same rounding points.
+        if (INTERIOR && p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {
+            const unsigned voff = (unsigned)(lane >> 3) * (unsigned)p.ldo + (unsigned)(n_base + 8 * rc);
+            const unsigned roff = (unsigned)(lane >> 3) * (unsigned)p.ldres + (unsigned)(n_base + 8 * rc);
+            f32x4 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n_base + j * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                char* blk = st + (i & 1) * 2048;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[j][i];
+                    if (p.bias) v += bv[j];
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+                    const int chunk = 2 * j + (g >> 1);
+                    *reinterpret_cast<bf16x4*>(blk + li * 128 + ((chunk ^ (li & 7)) << 4) + (g & 1) * 8) = o;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int rr = (lane >> 3) + 8 * h;
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(blk + rr * 128 + ((rc ^ (rr & 7)) << 4));
+                    const long mrow = m_base + i * 16 + 8 * h;                   // uniform
+                    if (p.res_kind == 2) {                                   // MLX bf16 add: both operands bf16, sum rounded once
+                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>((const bf16*)p.res + mrow * p.ldres + roff);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
+                    }
+                    *reinterpret_cast<bf16x8*>((bf16*)p.out + mrow * p.ldo + voff) = v;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             char* blk = st + (i & 1) * 2048;
@@ -198,6 +262,35 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     // fp32 out (+ optional fp32 residual): 16 rows x 64 columns per block (256-byte rows), one block in flight
     const int rc = lane & 15;
     const int n = n_base + 4 * rc;
+    if (INTERIOR && p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {   // interior sub-tile: see the bf16 path above
+        const unsigned voff = (unsigned)(lane >> 4) * (unsigned)p.ldo + (unsigned)(n_base + 4 * rc);
+        const unsigned roff = (unsigned)(lane >> 4) * (unsigned)p.ldres + (unsigned)(n_base + 4 * rc);
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n_base + j * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[j][i];
+                if (p.bias) v += bv[j];
+                if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                *reinterpret_cast<f32x4*>(st + li * 256 + (((4 * j + g) ^ li) << 4)) = v;
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int rr = (lane >> 4) + 4 * h;
+                f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * 256 + ((rc ^ rr) << 4));
+                const long mrow = m_base + i * 16 + 4 * h;                       // uniform
+                if (p.res_kind == 1) v += *reinterpret_cast<const f32x4*>((const float*)p.res + mrow * p.ldres + roff);
+                *reinterpret_cast<f32x4*>((float*)p.out + mrow * p.ldo + voff) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -808,7 +901,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
                 }
             }
         }
-        if (p.lds_epi) gemm_epilogue_lds<MI>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
+        if (p.lds_epi) gemm_epilogue_lds<MI, true>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);   // the conv variant has no register to spare for a second path
         else gemm_epilogue<MI>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, g, li);
         G8_STAMP();                                                         // 3 + 2t: epilogue of tile t issued
         v += gridDim.x;
@@ -820,6 +913,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
 }
 
 static int g_gemm_mode = 0;                                  // q3asr_gemm_force_kernel
+static int g_gemm_interior = 1;                              // q3asr_gemm_set_interior (A/B hook): 0 = every tile takes the general epilogue
+extern "C" int q3asr_gemm_set_interior(int on) { int was = g_gemm_interior; g_gemm_interior = on ? 1 : 0; return was; }
 static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_stamp
 
 // Diagnostic hook: workgroup 0 of every following 8-phase launch writes up to 16 wall_clock64() stamps (100 MHz) to `buf`
@@ -864,6 +959,8 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
         p8.lds_epi = p.N % 8 == 0 && p.ldo % 8 == 0 && ((uintptr_t)p.out & 15) == 0 && (p.ldo * esz) % 16 == 0 &&
                      (p.res_kind == 0 || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
                      (!p.bias || ((uintptr_t)p.bias & 15) == 0);
+        // 2: interior sub-tiles may take the short epilogue (32-bit lane offsets: the output and the residual must span < 4 Gi elements)
+        if (p8.lds_epi && g_gemm_interior && (long)p.M * p.ldo < (1L << 32) && (p.res_kind == 0 || (long)p.M * p.ldres < (1L << 32))) p8.lds_epi = 2;
         static std::atomic<bool> attr8{false};
         if (!attr8) {
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
@@ -985,7 +1082,7 @@ extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale,
     else Q3_REQUIRE(ldo % 8 == 0 && ldo >= N, "gemm_fp8: ldo=%ld must be >= N and a multiple of 8", (long)ldo);
     Q3_REQUIRE(((uintptr_t)out & 15) == 0 && ((uintptr_t)w_scale & 15) == 0 && (res_kind == 0 || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0)),
                "gemm_fp8: out / w_scale / res must be 16-byte aligned");
-    p.lds_epi = 1;
+    p.lds_epi = g_gemm_interior ? 2 : 1;
     const unsigned tiles256 = (unsigned)((M + G2_T - 1) / G2_T) * (unsigned)((N + G2_T - 1) / G2_T);
     static std::atomic<bool> attr{false};
     if (!attr) {
