@@ -67,6 +67,11 @@ int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int 
 int q3asr_gemm_force_kernel(int mode);
 /* Diagnostic: 0 = every sub-tile of the 8-phase kernels takes the general (bounds-tested) epilogue, 1 = interior sub-tiles take the short one (default). Same bits either way; returns the previous setting. Used by tools/ab_gemm_epilogue.py */
 int q3asr_gemm_set_interior(int on);
+/* Diagnostic: switches between two launch forms with identical results, for A/B measurements in one process (tools/ab_step.py,
+ * tools/bench_head.py).  Every option defaults to 1; returns the previous value, or -1 for an unknown option.  A captured
+ * graph keeps the form it was captured with. */
+#define Q3ASR_OPT_HEAD_XCD_MAP 1    /* tied head: workgroups that share a 128-byte logits line run on one XCD */
+int q3asr_set_option(int option, int value);
 /* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
 int q3asr_gemm_set_stamp(void* buf);
 

@@ -50,6 +50,7 @@ _SIGS = {
     "q3asr_graph_destroy": [_vp],
     "q3asr_gemm_force_kernel": [_i],
     "q3asr_gemm_set_interior": [_i],
+    "q3asr_set_option": [_i, _i],
     "q3asr_gemm_set_stamp": [_vp],
     "q3asr_event_create": [C.POINTER(_vp)],
     "q3asr_event_record": [_vp, _vp],

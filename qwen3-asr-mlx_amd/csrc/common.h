@@ -19,6 +19,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define Q3_ELAUNCH (-2)
 
 extern "C" void q3asr_set_error(const char* fmt, ...);
+// A/B switches of launch forms that do not change results (q3asr_set_option, include/q3asr.h); read by the launchers only
+extern int g_q3_option[8];
+#define Q3ASR_OPT_HEAD_XCD_MAP 1      // the ids of include/q3asr.h
 int q3_check_launch(const char* what);
 
 #define Q3_REQUIRE(cond, ...)                 \

@@ -374,15 +374,27 @@ extern "C" int q3asr_skinny3_gemm_norm(const float* in_slab, int in_n_slabs, int
 template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, bool FUSE = false>
 __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restrict__ X16, const void* __restrict__ Wt, int M, int N, int K,
                                                              const float* __restrict__ w_scale, float* __restrict__ slab,
-                                                             bf16* __restrict__ out, long ldo, const FuseNorm fz) {
+                                                             bf16* __restrict__ out, long ldo, const FuseNorm fz, int xcd_map) {
     static_assert(!F8 || NKS % 2 == 0, "fp8 fragments come in pairs of k steps");
     static_assert(EPI != 2 || TPW % 2 == 0, "SwiGLU needs whole (gate, up) tile pairs per workgroup");
     static_assert(!FUSE || (MT == 1 && WAVES >= 4), "fused norm: M <= 2, at least 256 threads");
     extern __shared__ f32x4 red4[];                          // [WAVES][TPW][MT][64] | FUSE: x rows [2][K] bf16 | K floats
     __shared__ float fred4[4];
-    constexpr int MC = MT < 2 ? MT : 2;                      // m-tiles per pass
+    // m-tiles per pass.  The tied head at 17-32 rows takes its two m-tiles one after the other: 113 instead of 137 VGPRs, so two
+    // workgroups share a CU and one's loads fly while the other reduces and stores (106.2 -> 101.6 us at 32 rows; same sums).
+    constexpr int MC = (MT < 2 || (EPI == 1 && MT == 2)) ? 1 : 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int t0 = blockIdx.x * TPW;
+    int bx = blockIdx.x;
+    if (EPI == 1 && xcd_map) {
+        // The tied head writes 32 * TPW bytes per row and workgroup: half a 128-byte line at TPW = 2.  Consecutive workgroups
+        // go to consecutive XCDs (each with an L2 of its own), so the two halves of a line would be written back separately,
+        // as partial lines (0.33 us per logits row measured, 0.12 with whole lines).  Workgroup b therefore takes tile group
+        // (b % 8) * (grid / 8) + b / 8: neighbours in n are neighbours in time on ONE XCD and their halves meet in its L2.
+        // The launcher rounds the grid up to a multiple of 8; the surplus workgroups leave here, before any barrier.
+        bx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        if (bx * TPW >= (N >> 4)) return;
+    }
+    const int t0 = bx * TPW;
     const int ks0 = (blockIdx.y * WAVES + wave) * NKS;
     const bf16* xp = X16 + (long)ks0 * MT * 512 + lane * 8;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restr
 
 template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, bool FUSE>
 static void skinny4_go(dim3 grid, hipStream_t s, const void* X16, const FuseNorm& fz, const void* W, int M, int N, int K, const float* w_scale,
-                       float* slab, void* out, long ldo) {
+                       float* slab, void* out, long ldo, int xcd_map) {
     constexpr size_t image = (size_t)WAVES * TPW * MT * 64 * sizeof(f32x4);
     static_assert(image <= 160 * 1024, "skinny4: partial-sum image exceeds LDS");
     const size_t lds = image + (FUSE ? (size_t)K * 8 : 0);   // + two bf16 rows and K floats
@@ -512,7 +524,7 @@ static void skinny4_go(dim3 grid, hipStream_t s, const void* X16, const FuseNorm
         granted.store(lds, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((skinny4_kernel<MT, TPW, NKS, EPI, WAVES, F8, FUSE>), grid, dim3(64 * WAVES), lds, s, (const bf16*)X16, W, M, N, K, w_scale,
-                       slab, (bf16*)out, ldo, fz);
+                       slab, (bf16*)out, ldo, fz, xcd_map);
 }
 
 // The instantiated geometries (tiles per workgroup, k-steps per wave, waves), by epilogue; ops.gemm_geometry4 holds the same
@@ -541,13 +553,14 @@ static int skinny4_launch(const char* who, const void* X16, const FuseNorm* fuse
         Q3_REQUIRE(K % 8 == 0 && (size_t)waves * tiles_per_wg * 1024 + (size_t)K * 8 <= 160 * 1024, "%s: K=%d too large for the fused activation image", who, K);
     }
     const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-    dim3 grid(N / 16 / tiles_per_wg, S);
+    const int xcd_map = epi == 1 && g_q3_option[Q3ASR_OPT_HEAD_XCD_MAP];
+    dim3 grid(xcd_map ? (N / 16 / tiles_per_wg + 7) / 8 * 8 : N / 16 / tiles_per_wg, S);   // see the XCD note in the kernel
     hipStream_t s = (hipStream_t)stream;
     bool done = false;
 #define Q3_TRY(MT_, TPW_, NKS_, EPI_, WAVES_, F8_, FUSE_)                                                                              \
     if (!done && MT == MT_ && tiles_per_wg == TPW_ && ksteps_per_wave == NKS_ && epi == EPI_ && waves == WAVES_ && (w_scale != nullptr) == F8_ && \
         (fuse != nullptr) == FUSE_) {                                                                                                  \
-        skinny4_go<MT_, TPW_, NKS_, EPI_, WAVES_, F8_, FUSE_>(grid, s, X16, fz, W16, M, N, K, w_scale, slab, out, (long)ldo);          \
+        skinny4_go<MT_, TPW_, NKS_, EPI_, WAVES_, F8_, FUSE_>(grid, s, X16, fz, W16, M, N, K, w_scale, slab, out, (long)ldo, xcd_map); \
         done = true;                                                                                                                   \
     }
 #define Q3_TRY_F8(MT_, TPW_, NKS_, EPI_, WAVES_, FUSE_)                                 \
