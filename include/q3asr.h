@@ -71,6 +71,7 @@ int q3asr_gemm_set_interior(int on);
  * tools/bench_head.py).  Every option defaults to 1; returns the previous value, or -1 for an unknown option.  A captured
  * graph keeps the form it was captured with. */
 #define Q3ASR_OPT_HEAD_XCD_MAP 1    /* tied head: workgroups that share a 128-byte logits line run on one XCD */
+#define Q3ASR_OPT_HEAD_STREAM 2     /* tied head (bf16, K = 2048, geometry 2/8/8, <= 32 rows): one workgroup per CU walking its tile groups */
 int q3asr_set_option(int option, int value);
 /* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
 int q3asr_gemm_set_stamp(void* buf);

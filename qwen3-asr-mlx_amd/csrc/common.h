@@ -22,6 +22,7 @@ extern "C" void q3asr_set_error(const char* fmt, ...);
 // A/B switches of launch forms that do not change results (q3asr_set_option, include/q3asr.h); read by the launchers only
 extern int g_q3_option[8];
 #define Q3ASR_OPT_HEAD_XCD_MAP 1      // the ids of include/q3asr.h
+#define Q3ASR_OPT_HEAD_STREAM 2
 int q3_check_launch(const char* what);
 
 #define Q3_REQUIRE(cond, ...)                 \

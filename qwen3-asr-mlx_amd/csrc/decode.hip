@@ -512,6 +512,94 @@ __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// The tied head as one workgroup per CU that walks its tile groups (bf16 weights, K = 2,048, the (2, 8, 8) geometry of
+// skinny4_kernel: 2 weight tiles per group, 8 waves x 8 k-steps).  A slot of skinny4_kernel runs ~9 workgroups per launch of
+// the head, each re-reading its X fragments from L2 (128 KB at 17-32 rows, as much as its weights) and paying a workgroup's
+// start and drain; here the X fragments stay in registers, the next group's weights are requested before the current
+// group's MFMAs (two register buffers), and the partial-sum image in LDS is double-buffered so that one barrier per group
+// suffices.  Same sums in the same order as skinny4_kernel<MT, 2, 8, 1, 8>: bit-identical logits.
+// Workgroup b serves XCD b % 8's contiguous share of the groups (see the XCD note in skinny4_kernel), taking groups
+// b / 8, b / 8 + gridDim.x / 8, ... of it, so neighbouring groups are written at about the same time through one L2.
+// ---------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(512) void head_stream_kernel(const bf16* __restrict__ X16, const bf16* __restrict__ W16, int M, int N,
+                                                          bf16* __restrict__ out, long ldo) {
+    constexpr int TPW = 2, NKS = 8, WAVES = 8, KS = 64;     // KS: k-steps of 32 in K = 2,048
+    extern __shared__ f32x4 redp[];                          // [2][WAVES][TPW][MT][64]
+    constexpr int IMG = WAVES * TPW * MT * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int ks0 = wave * NKS;
+    bf16x8 xf[NKS][MT];
+    {
+        const bf16* xp = X16 + (long)ks0 * MT * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NKS; ++i)
+#pragma unroll
+            for (int mc = 0; mc < MT; ++mc) xf[i][mc] = *reinterpret_cast<const bf16x8*>(xp + ((long)i * MT + mc) * 512);
+    }
+    const int P = (N >> 4) / TPW, per = (P + 7) >> 3;
+    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+    int j = blockIdx.x >> 3;                                 // index inside the XCD's share
+    bf16x8 wA[NKS][TPW], wB[NKS][TPW];
+    auto load = [&](bf16x8 (&w)[NKS][TPW], int jj) {
+        const bf16* wp = W16 + ((long)(xcd * per + jj) * TPW * KS + ks0) * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NKS; ++i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) w[i][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + ((long)t * KS + i) * 512));
+    };
+    auto finish = [&](const bf16x8 (&w)[NKS][TPW], int jj, int buf) {
+        f32x4 acc[TPW][MT];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int mc = 0; mc < MT; ++mc) acc[t][mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NKS; ++i)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int mc = 0; mc < MT; ++mc) acc[t][mc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][t], xf[i][mc], acc[t][mc], 0, 0, 0);
+        f32x4* red = redp + buf * IMG;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int mc = 0; mc < MT; ++mc) red[((wave * TPW + t) * MT + mc) * 64 + lane] = acc[t][mc];
+        __syncthreads();                                     // the only barrier of a group: the other image is being filled meanwhile
+        const int t0 = (xcd * per + jj) * TPW;
+        for (int c = wave; c < TPW * MT; c += WAVES) {
+            const int t = c / MT, mt = c - t * MT;
+            f32x4 a = red[(t * MT + mt) * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < WAVES; ++ww) a += red[((ww * TPW + t) * MT + mt) * 64 + lane];
+            const int m = 16 * mt + li;
+            if (m >= M) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(a[r]);
+            *reinterpret_cast<bf16x4*>(out + (long)m * ldo + 16 * (t0 + t) + 4 * g) = o;
+        }
+    };
+    // Loads are unconditional (past the end they re-read the share's last group and are dropped): the compiler then counts
+    // vmcnt exactly, and the MFMAs of a group wait for that group's 16 loads only, with the next group's 16 in flight.
+    const int n_mine = min(per, P - xcd * per);              // groups in this XCD's share
+    const int cnt = n_mine > j ? (n_mine - j + nslot - 1) / nslot : 0;      // ... of which this workgroup's
+    if (cnt == 0) return;                                    // (small N)
+    const int last = n_mine - 1;
+    load(wA, j);
+    for (int k = 0; k < cnt; k += 2) {
+        load(wB, min(j + nslot, last));
+        __builtin_amdgcn_sched_barrier(0);                   // the next group's loads are issued before this group's MFMAs
+        finish(wA, j, 0);
+        load(wA, min(j + 2 * nslot, last));
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < cnt) finish(wB, j + nslot, 1);
+        j += 2 * nslot;
+    }
+}
+
 template <int MT, int TPW, int NKS, int EPI, int WAVES, bool F8, bool FUSE>
 static void skinny4_go(dim3 grid, hipStream_t s, const void* X16, const FuseNorm& fz, const void* W, int M, int N, int K, const float* w_scale,
                        float* slab, void* out, long ldo, int xcd_map) {
@@ -557,6 +645,16 @@ static int skinny4_launch(const char* who, const void* X16, const FuseNorm* fuse
     dim3 grid(xcd_map ? (N / 16 / tiles_per_wg + 7) / 8 * 8 : N / 16 / tiles_per_wg, S);   // see the XCD note in the kernel
     hipStream_t s = (hipStream_t)stream;
     bool done = false;
+    if (epi == 1 && !fuse && !w_scale && K == 2048 && tiles_per_wg == 2 && ksteps_per_wave == 8 && waves == 8 && MT == 2 &&
+        g_q3_option[Q3ASR_OPT_HEAD_STREAM]) {
+        // the tied head: persistent form of this geometry (head_stream_kernel), bit-identical
+        const int groups = N / 32;
+        const int wgs = groups >= 256 ? 256 : (groups + 7) / 8 * 8;                  // one workgroup per CU, a multiple of 8
+        const size_t lds = (size_t)2 * 8 * 2 * MT * 64 * sizeof(f32x4);
+        if (MT == 1) hipLaunchKernelGGL(head_stream_kernel<1>, dim3(wgs), dim3(512), lds, s, (const bf16*)X16, (const bf16*)W16, M, N, (bf16*)out, (long)ldo);
+        else hipLaunchKernelGGL(head_stream_kernel<2>, dim3(wgs), dim3(512), lds, s, (const bf16*)X16, (const bf16*)W16, M, N, (bf16*)out, (long)ldo);
+        return q3_check_launch(who);
+    }
 #define Q3_TRY(MT_, TPW_, NKS_, EPI_, WAVES_, F8_, FUSE_)                                                                              \
     if (!done && MT == MT_ && tiles_per_wg == TPW_ && ksteps_per_wave == NKS_ && epi == EPI_ && waves == WAVES_ && (w_scale != nullptr) == F8_ && \
         (fuse != nullptr) == FUSE_) {                                                                                                  \

@@ -933,6 +933,33 @@ def test_skinny4_matches_reference_and_is_batch_invariant(dev, N, K, epi, geo, f
             assert torch.equal(results[M], big[:M]), f"rows differ between M={M} and M={Ms[-1]}"
 
 
+@pytest.mark.parametrize("N,M", [(151936, 32), (151936, 17), (9504, 32), (4128, 20), (224, 32), (32, 17)])
+def test_tied_head_launch_forms_give_identical_logits(dev, N, M):
+    """The tied head at 17-32 rows (bf16, K = 2048, geometry 2/8/8) runs as one workgroup per CU walking its tile groups
+    (head_stream_kernel); q3asr_set_option switches to one workgroup per group and to grid-order tile groups.  All forms:
+    the same logits bit for bit, for group counts that are / are not multiples of 8 and fewer groups than XCDs."""
+    from qwen3_asr_mlx_amd import _lib, ops
+    K = 2048
+    X, W = rnd((M, K), dev, 172), rnd((N, K), dev, 173, 1.0 / math.sqrt(K))
+    x16, wt = ops.to_x16(X), ops.to_w16(W)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for stream, xmap in ((1, 1), (0, 1), (0, 0)):
+            lib.q3asr_set_option(2, stream)
+            lib.q3asr_set_option(1, xmap)
+            out = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=dev)      # a guard row behind the last one
+            ops.skinny4(x16, M, wt, N, K, 1, 2, 8, 8, out=out)
+            outs[(stream, xmap)] = out
+    finally:
+        lib.q3asr_set_option(2, 1)
+        lib.q3asr_set_option(1, 1)
+    ref = bfr(X.float().cpu() @ W.float().cpu().T)
+    torch.testing.assert_close(outs[(1, 1)][:M].float().cpu(), ref, atol=2e-2, rtol=8e-3)
+    assert torch.equal(outs[(1, 1)], outs[(0, 1)]) and torch.equal(outs[(1, 1)], outs[(0, 0)])
+    assert bool((outs[(1, 1)][M] == 7.0).all())
+
+
 def test_skinny4_tile_count_does_not_change_bits(dev):
     """(4, 4, 16) and (2, 4, 16) -- what the decoder switches between at 32 / 33 rows -- give identical SwiGLU outputs."""
     from qwen3_asr_mlx_amd import ops

@@ -28,12 +28,29 @@ for M in (1, 8, 16, 17, 24, 32):
             torch.cuda.synchronize()
             if rnd:
                 ts.append(e0.elapsed_time(e1) * 1000 / 12)
+        from qwen3_asr_mlx_amd import _lib
+        _lib.load().q3asr_set_option(2, 0)                                        # the per-group launch form of the same geometry
+        tt = []
+        for rnd in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(12):
+                ops.skinny4(x16, M, Ws[i % 3], N, K, 1, tpw, nks, waves, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd:
+                tt.append(e0.elapsed_time(e1) * 1000 / 12)
+        out0 = out.clone()
+        _lib.load().q3asr_set_option(2, 1)
         ops.skinny4(x16, M, Ws[0], N, K, 1, tpw, nks, waves, out=out)
         torch.cuda.synchronize()
+        same0 = bool(torch.equal(out, out0)) if False else None
         same = ""
         if ref is None:
             ref = out.clone()
         else:
             same = f"  same bits as {geos[0]}: {bool(torch.equal(ref, out))}"
         t = sorted(ts)[len(ts) // 2]
-        print(f"M={M:2d} geometry {g}: {t:6.1f} us  {N * K * 2 / t / 1e6:5.2f} TB/s{same}", flush=True)
+        ops.skinny4(x16, M, Ws[2], N, K, 1, tpw, nks, waves, out=out)
+        torch.cuda.synchronize()
+        print(f"M={M:2d} geometry {g}: {t:6.1f} us  {N * K * 2 / t / 1e6:5.2f} TB/s   one workgroup per group {sorted(tt)[len(tt) // 2]:6.1f} us (same bits: {bool(torch.equal(out, out0))}){same}", flush=True)
