@@ -548,7 +548,7 @@ def main() -> None:
                 break
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
-                            "kernel": "skinny4_kernel (decode weight streaming, all shapes of one step)",
+                            "kernel": "skinny4_kernel + head_stream_kernel (decode weight streaming, all shapes of one step)",
                             "launches_measured": launches, "avg_launch_us": 1e3 * avg_ms,
                             "bytes_per_launch": sum(per_launch) / len(per_launch),
                             "measured_on": "a hipGraph of the step's 113 weight-streaming launches alone (HIP events on the launch stream)",

@@ -10,14 +10,14 @@ import sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 meta = json.load(open(sys.argv[2]))
-gemm = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if "skinny4_kernel" in r["Kernel_Name"] or "skinny3_kernel" in r["Kernel_Name"]]
+gemm = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if any(k in r["Kernel_Name"] for k in ("skinny4_kernel", "skinny3_kernel", "head_stream_kernel"))]
 starts = [int(r["Start_Timestamp"]) for r in rows if "embed_norm_x16" in r["Kernel_Name"]]
 periods = sorted(b - a for a, b in zip(starts, starts[1:]))
 # consecutive steps of one graph replay sit back to back: the lower half of the periods excludes replay boundaries and the eager step
 per = periods[: max(1, len(periods) // 2)]
 by_kernel = {}
 for r in rows:
-    if "skinny" in r["Kernel_Name"] or "attn_decode" in r["Kernel_Name"] or "resnorm" in r["Kernel_Name"] or "sample_" in r["Kernel_Name"] or "embed_norm" in r["Kernel_Name"]:
+    if "skinny" in r["Kernel_Name"] or "head_stream" in r["Kernel_Name"] or "attn_decode" in r["Kernel_Name"] or "resnorm" in r["Kernel_Name"] or "sample_" in r["Kernel_Name"] or "embed_norm" in r["Kernel_Name"]:
         k = (r["Kernel_Name"].split("(")[0][:60], r["Grid_Size_X"], r["Grid_Size_Y"])
         by_kernel.setdefault(k, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 out = {"lib_sha16": meta.get("lib_sha16"), "batch": meta.get("batch"), "launches": len(gemm), "avg_launch_us": sum(gemm) / len(gemm) / 1e3,

@@ -30,7 +30,7 @@ for key in sorted(fetch, key=lambda k: -sum(fetch[k])):
     rows.append({"kernel": key[0], "grid_threads": key[1], "wg": key[2], "dispatches": len(f),
                  "FETCH_SIZE_KB_avg": round(sum(f) / len(f), 1), "hbm_read_MB_corrected_x2": round(2 * sum(f) / len(f) * 1024 / 1e6, 2),
                  "WRITE_SIZE_KB_avg": round(sum(w) / len(w), 1), "hbm_write_MB": round(sum(w) / len(w) * 1024 / 1e6, 2)})
-sk = [r for r in rows if "skinny4_kernel" in r["kernel"] or "skinny3_kernel" in r["kernel"]]
+sk = [r for r in rows if any(k in r["kernel"] for k in ("skinny4_kernel", "skinny3_kernel", "head_stream_kernel"))]
 n = sum(r["dispatches"] for r in sk)
 meta = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else {}
 out = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/pmc_probe.py " + ",".join(meta.get("ran", ["?"])) +
