@@ -1082,7 +1082,7 @@ extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale,
     else Q3_REQUIRE(ldo % 8 == 0 && ldo >= N, "gemm_fp8: ldo=%ld must be >= N and a multiple of 8", (long)ldo);
     Q3_REQUIRE(((uintptr_t)out & 15) == 0 && ((uintptr_t)w_scale & 15) == 0 && (res_kind == 0 || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0)),
                "gemm_fp8: out / w_scale / res must be 16-byte aligned");
-    p.lds_epi = g_gemm_interior ? 2 : 1;
+    p.lds_epi = (g_gemm_interior && (long)M * ldo < (1L << 32) && (res_kind == 0 || (long)M * ldres < (1L << 32))) ? 2 : 1;   // as in gemm_launch
     const unsigned tiles256 = (unsigned)((M + G2_T - 1) / G2_T) * (unsigned)((N + G2_T - 1) / G2_T);
     static std::atomic<bool> attr{false};
     if (!attr) {

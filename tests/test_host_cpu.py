@@ -45,6 +45,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"null pointer" in h.q3asr_last_error()
     with pytest.raises(ValueError):
         q._lib.call("q3asr_skinny4_gemm", None, 1, None, None, 64, 256, 0, 2, 2, 8, None, None, 64, None)
+    # the A/B switches between launch forms: previous value back, unknown ids refused
+    assert h.q3asr_set_option(1, 0) == 1 and h.q3asr_set_option(1, 1) == 0 and h.q3asr_set_option(2, 1) == 1
+    assert h.q3asr_set_option(7, 1) == -1 and b"unknown option" in h.q3asr_last_error()
+    assert h.q3asr_gemm_set_interior(1) == 1
 
 
 def test_filterbank_and_prompt_and_splitter_match_fixtures():
