@@ -121,6 +121,145 @@ def cpu_baseline(cfg, state, clip, n_dec_sample: int, n_dec_full: int, threads: 
     }
 
 
+def decode_gemm_roofline(model, cfg, B: int, ndec: int, bytes_per_weight: int, dev):
+    """Roofline of the dominant kernel (decode weight streaming: skinny4_kernel / head_stream_kernel; skinny3_kernel where no
+    skinny4 geometry fits).  HIP events on the launch stream around R back-to-back "GEMM-only" decode steps: exactly the 113
+    weight-streaming launches of a step (4 per layer over all 28 layers' distinct weights, so no cache reuse between launches,
+    + the tied head), same operands and split factors as the timed region, captured into a hipGraph and replayed (as the
+    decode step itself runs: issued one by one from Python they are host-bound at ~8 us per launch)."""
+    import torch
+    from qwen3_asr_mlx_amd import _lib
+    dec = model._decoder
+    ws = dec.workspace(B, ndec)
+    e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+    lib = _lib.load()
+    lib.q3asr_event_create(C.byref(e0))
+    lib.q3asr_event_create(C.byref(e1))
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        stream = C.c_void_p(side.cuda_stream)
+        dec.gemm_only_step(ws)                                       # warm (code objects, LDS attributes)
+        _lib.call("q3asr_graph_begin", stream)
+        try:
+            per_step = dec.gemm_only_step(ws)
+        finally:
+            graph = C.c_void_p()
+            _lib.call("q3asr_graph_end", stream, C.byref(graph))
+        _lib.call("q3asr_graph_launch", graph, stream)               # warm replay
+        R = 20
+        _lib.check(lib.q3asr_event_record(e0, stream), "event_record")
+        for _ in range(R):
+            _lib.call("q3asr_graph_launch", graph, stream)
+        _lib.check(lib.q3asr_event_record(e1, stream), "event_record")
+        side.synchronize()
+        _lib.check(lib.q3asr_event_elapsed_ms(e0, e1, C.byref(ms)), "event_elapsed")
+        _lib.call("q3asr_graph_destroy", graph)
+    lib.q3asr_event_destroy(e0)
+    lib.q3asr_event_destroy(e1)
+    launches = per_step * R
+    per_launch = decode_bytes_per_launch(cfg, B, bytes_per_weight)
+    total_bytes = sum(per_launch) * R
+    avg_ms = ms.value / launches
+    achieved = total_bytes / (ms.value * 1e-3) / 1e9
+    log(f"roofline leg ({bytes_per_weight} B/weight, batch {B}): {launches} decode GEMM launches in {ms.value:.2f} ms")
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "kernel": "skinny4_kernel + head_stream_kernel (decode weight streaming, all shapes of one step)",
+            "launches_measured": launches, "avg_launch_us": 1e3 * avg_ms, "bytes_per_launch": sum(per_launch) / len(per_launch),
+            "measured_on": "a hipGraph of the step's 113 weight-streaming launches alone (HIP events on the launch stream)"}
+
+
+def sampler_times(model, cfg, B: int, dev, reps: int = 40):
+    """us per q3asr_sample_step launch on bf16 logits [B][V] ~ N(0, 3^2): greedy + penalty 1.2 (the headline's sampler) beside
+    temperature 0.7 / top-p 0.9 + penalty 1.2 (BASELINE.json configs[4]); HIP events around `reps` back-to-back launches."""
+    import torch
+    from qwen3_asr_mlx_amd.decoder import DecodeWorkspace
+    dec = model._decoder
+    out = {}
+    for name, sm in (("greedy_us", {"temperature": 0.0, "top_p": 1.0}), ("t0.7_top_p0.9_us", {"temperature": 0.7, "top_p": 0.9})):
+        ws = DecodeWorkspace(cfg.text_decoder, B, reps + 8, dev, fp8=getattr(dec, "weight_dtype", "bf16") != "bf16")
+        ws.logits.copy_((torch.randn(ws.logits.shape, device=dev) * 3.0).to(torch.bfloat16))
+        ws.max_new.fill_(reps + 8)
+        sampling = {"temperature": sm["temperature"], "top_p": sm["top_p"], "top_k": 0, "repetition_penalty": 1.2, "repetition_context_size": 100, "seed": 7}
+        dec.sample_step(ws, ws.logits, sampling)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dec.sample_step(ws, ws.logits, sampling)
+        e1.record()
+        e1.synchronize()
+        out[name] = 1e3 * e0.elapsed_time(e1) / reps
+        assert int(ws.finished.sum()) == 0
+    return out
+
+
+def longform_fp8_leg(cfg, state, dev, q, synth, ndec: int = 128, minutes: int = 20):
+    """BASELINE.json configs[4]: Qwen3-ASR-1.7B with fp8 decoder weights (prefill fp8 x fp8 on the CDNA4 fp8 MFMA, W8A16 decode
+    steps), 20 min of synthetic audio, low-energy chunking at chunk_duration = 30 (reference model.py:382-447,454-513), temperature
+    0.7 / top-p 0.9 / repetition penalty 1.2.  Host float32 array in, text out: split points, H2D, mel, encoder, prefill, decode and
+    detokenisation are all inside the timed region.  Two budgets: SURVEY.md 8d's N_dec = 128 per 30 s segment (comparable with the
+    headline), through Qwen3ASR._run_jobs -- what _transcribe_chunked runs after it has fixed the budgets -- and the reference's own
+    rule max(256, 50 / s) = 1,500 tokens per segment through the public transcribe() (random weights never emit EOS: every segment
+    decodes its whole budget, the worst case of that rule)."""
+    import torch
+    from qwen3_asr_mlx_amd.model import _find_split_points
+    from signals import signal
+    log("longform_fp8: building the fp8 model")
+    m8 = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype="fp8")
+    audio = np.concatenate([signal("speechlike", 16000 * 60, seed=100 + i) for i in range(minutes)])
+    secs = len(audio) / 16000.0
+
+    def run_fixed(budget: int):
+        pts = _find_split_points(audio, 30 * 16000, 5 * 16000)
+        jobs, prev = [], 0
+        for sp in pts + [len(audio)]:
+            seg = audio[prev:sp]
+            prev = sp
+            if len(seg):
+                jobs.append((0, seg, budget))
+        texts = m8._run_jobs(jobs, "English", 0.7, 0.9, 0, 1.2, 100)
+        return len(jobs), " ".join(t_ for t_ in texts if t_)
+
+    def timed(fn, reps):
+        lat, r = [], None
+        for i in range(reps + 1):                              # the first run is the warm-up (workspace, graph capture)
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            if i:
+                lat.append(time.perf_counter() - s0)
+        return r, float(np.median(lat))
+
+    (n_seg, text), t128 = timed(lambda: run_fixed(ndec), 3)
+    assert n_seg == 40 and len(text) > 0
+    log(f"longform_fp8: {n_seg} segments x {ndec} tokens: {1e3 * t128:.1f} ms, RTF {secs / t128:.0f}x")
+    r_ref, t_ref = timed(lambda: m8.transcribe(audio, temperature=0.7, top_p=0.9, chunk_duration=30.0), 1)
+    assert r_ref.duration == secs and len(r_ref.text) > 0
+    log(f"longform_fp8: reference budget (1,500 tokens/segment): {t_ref:.2f} s, RTF {secs / t_ref:.0f}x")
+    B = n_seg
+    roof = decode_gemm_roofline(m8, cfg, B, ndec, 1, dev)
+    smp = sampler_times(m8, cfg, B, dev)
+    # the step's algorithmic bytes: 1.72 GB of fp8 weights + B * L * 114,688 B of K/V (bf16) at the mean context of the run
+    l_bar = 408 + ndec / 2.0
+    step_bytes = 1.7205e9 + B * l_bar * 114688
+    out = {"value": secs / t128, "unit": "audio-s/wall-s", "p50_latency_ms": 1e3 * t128,
+           "workload": f"Qwen3-ASR-1.7B fp8 decoder weights, {minutes} min of audio as ONE request, chunk_duration 30 -> {n_seg} segments decoded as one "
+                       f"batch, temperature 0.7 / top-p 0.9 / repetition penalty 1.2, {ndec} decoded tokens per segment (SURVEY.md 8d), "
+                       "host array in -> text out (split points, H2D, detokenisation inside)",
+           "reference_budget": {"value": secs / t_ref, "unit": "audio-s/wall-s", "latency_ms": 1e3 * t_ref,
+                                "workload": "the same request through the public transcribe(): the reference's budget max(256, 50/s) = 1,500 tokens per segment, "
+                                            "all decoded (no EOS with random weights)", "ms_per_token": 1e3 * t_ref / 1499.0},
+           "roofline": {**roof, "step_algorithmic_bytes": step_bytes,
+                        "note": "fp8 weight streaming of one W8A16 decode step (1 byte per weight), batch = the request's 40 segments"},
+           "sampler": {**smp, "note": "q3asr_sample_step at batch 40 over 151,936 bf16 logits per row; the draw runs the histogram top-p + categorical path, greedy the argmax path"},
+           "dtype": "fp8-e4m3 decoder weights; prefill fp8 x fp8 MFMA (per-token e4m3 activations), decode bf16 activations; encoder bf16"}
+    m8.close()
+    del m8
+    torch.cuda.empty_cache()
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +276,7 @@ def main() -> None:
                     help="fp8: decoder weights quantised on load, prefill on the fp8 MFMA (BASELINE.json configs[4]; not the headline "
                          "config); fp8w: weight-only variant")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the ndec=1500 and 5 s secondary legs")
+    ap.add_argument("--no-longform", action="store_true", help="skip the configs[4] leg (fp8 weights, 20 min long-form, T = 0.7 / top-p 0.9)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -182,7 +322,7 @@ def main() -> None:
     model = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, weight_dtype=args.weights)
     log("model ready")
     model.use_graph = not args.no_graph
-    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
+    if not (rank == 0 and world == 1 and (not args.no_cpu_baseline or not args.no_longform)):
         del state
     B, n = args.batch, int(args.clip_seconds * 16000)
     budgets = [args.ndec] * B
@@ -317,19 +457,49 @@ def main() -> None:
     if world == 1:
         # ---- SURVEY.md 8d's end-to-end definition through the public API: host float32 arrays in (pinned staging + H2D over
         # PCIe inside the timed region), mel -> encoder -> prefill -> decode, texts out.  Never `value` (that is HBM-resident).
-        e2e = []
-        for i in range(4):
-            torch.cuda.synchronize()
-            s0 = time.perf_counter()
-            res_ = model.transcribe_batch(host_clips, max_tokens=args.ndec)
-            torch.cuda.synchronize()
-            if i:
-                e2e.append(time.perf_counter() - s0)
+        # Both staging forms of audio.pack_audio are run interleaved in this one process (A/B), the shipped default last;
+        # `h2d` says where `end_to_end - value` goes: host fill of the pinned buffer, the copies (HIP events around them), the rest.
+        from qwen3_asr_mlx_amd import audio as qaudio
+        default_mode = qaudio.PACK_MODE
+        e2e = {"single": [], "grouped": []}
+        h2d = {}
+        res_ = None
+        for i in range(5):
+            for mode in sorted(e2e, key=lambda m_: m_ == default_mode):      # the default runs second in each pair
+                qaudio.PACK_MODE = mode
+                st_ = qaudio.PACK_STATS = {}
+                torch.cuda.synchronize()
+                s0 = time.perf_counter()
+                res_ = model.transcribe_batch(host_clips, max_tokens=args.ndec)
+                torch.cuda.synchronize()
+                dt_ = time.perf_counter() - s0
+                qaudio.PACK_STATS = None
+                if i:
+                    e2e[mode].append(dt_)
+                    h2d.setdefault(mode, []).append(qaudio.pack_stats_finish(st_))
+        qaudio.PACK_MODE = default_mode
         assert len(res_) == B and all(isinstance(r_.text, str) for r_ in res_)
-        line["end_to_end"] = {"value": B * args.clip_seconds / float(np.median(e2e)), "unit": "audio-s/wall-s",
-                              "p50_latency_ms": 1e3 * float(np.median(e2e)), "conforms_to": "SURVEY.md 8d (H2D of the audio inside the timed region)",
-                              "note": "Qwen3ASR.transcribe_batch(list of host float32 arrays): H2D of the batch and detokenisation inside the timed region"}
-        log(f"end-to-end (H2D + detokenise): {line['end_to_end']['p50_latency_ms']:.1f} ms vs {line['p50_latency_ms']:.1f} ms resident")
+        med = {m_: float(np.median(v_)) for m_, v_ in e2e.items()}
+
+        def h2d_summary(mode):
+            recs = h2d[mode]
+            f_ = lambda k: float(np.median([r_[k] for r_ in recs]))          # noqa: E731
+            return {"mode": mode, "bytes": recs[0]["bytes"], "groups": recs[0]["groups"], "pinned": recs[0]["pinned"],
+                    "setup_ms": f_("setup_ms"), "host_fill_ms": f_("host_fill_ms"), "copy_issue_ms": f_("copy_issue_ms"),
+                    "copy_span_ms": f_("copy_span_ms"), "copy_GBps_over_span": recs[0]["bytes"] / (f_("copy_span_ms") * 1e-3) / 1e9,
+                    "host_total_ms": f_("host_total_ms"), "p50_latency_ms": 1e3 * med[mode]}
+        line["end_to_end"] = {"value": B * args.clip_seconds / med[default_mode], "unit": "audio-s/wall-s",
+                              "p50_latency_ms": 1e3 * med[default_mode], "conforms_to": "SURVEY.md 8d (H2D of the audio inside the timed region)",
+                              "note": "Qwen3ASR.transcribe_batch(list of host float32 arrays): H2D of the batch and detokenisation inside the timed region",
+                              "minus_resident_ms": 1e3 * med[default_mode] - line["p50_latency_ms"],
+                              "h2d": h2d_summary(default_mode),
+                              "h2d_other_form": h2d_summary("grouped" if default_mode == "single" else "single"),
+                              "h2d_note": "audio.pack_audio: host_fill = copying the request's rows into the pinned staging buffer, copy_span = first copy "
+                                          "issued -> last copy done on the device timeline (the grouped form's span contains the fills between its copies); "
+                                          "both forms interleaved in this process, 4 timed runs each, medians"}
+        log(f"end-to-end (H2D + detokenise): {line['end_to_end']['p50_latency_ms']:.1f} ms vs {line['p50_latency_ms']:.1f} ms resident "
+            f"[{default_mode}: fill {line['end_to_end']['h2d']['host_fill_ms']:.1f} ms, copy span {line['end_to_end']['h2d']['copy_span_ms']:.1f} ms; "
+            f"other form {line['end_to_end']['h2d_other_form']['p50_latency_ms']:.1f} ms]")
     if world == 1 and not args.no_extra_configs and args.weights == "bf16":
         # ---- secondary legs SURVEY.md 8d names: the reference's own token budget max(256, 50/s) = 1500 per 30 s clip,
         # and the 5 s configuration (32 tokens per clip)
@@ -423,17 +593,19 @@ def main() -> None:
         fe = q.audio.get_frontend(dev)
 
         def timed(fn, reps=1):
-            # the best of `reps` runs: the first run after the batches-in-flight legs can pay for a fresh multi-GB block of the
-            # caching allocator (one line showed encoder_ms = 120 that way, the timed steps beside it unchanged)
-            best, r = None, None
+            # reps > 1: one untimed warm-up call (the first run after the batches-in-flight legs can pay for a fresh multi-GB block
+            # of the caching allocator: one line showed encoder_ms = 120 that way), then the MEDIAN of `reps` timed runs
+            r = None
+            if reps > 1:
+                r = fn()
+            lat = []
             for _ in range(reps):
                 torch.cuda.synchronize()
                 s0 = time.perf_counter()
                 r = fn()
                 torch.cuda.synchronize()
-                dt_ = time.perf_counter() - s0
-                best = dt_ if best is None else min(best, dt_)
-            return r, best
+                lat.append(time.perf_counter() - s0)
+            return r, float(np.median(lat))
 
         (mel, n_frames), t_mel = timed(lambda: fe(audio, lens_dev, lens), 3)
         (feats, tok_counts), t_enc = timed(lambda: enc_.forward_batch(mel, n_frames), 3)
@@ -484,49 +656,14 @@ def main() -> None:
             "prefill_frac_of_2.5PF": B * 1170e9 * (T_avg / 408.0) / t_pre / 2.5e15,
             "decode_ms": 1e3 * t_dec, "decode_ms_per_token": 1e3 * t_dec / (args.ndec - 1),
             "decode_GBps": dec_bytes / t_dec / 1e9, "decode_frac_of_8TBps": dec_bytes / t_dec / 8e12,
-            "note": "one step re-run stage by stage with a device sync between stages (mel / encoder / prefill: best of 3; decode: the product loop, 4-step graph replays); work figures: SURVEY.md 8d "
+            "statistic": "mel / encoder / prefill: median of 3 after one untimed warm-up call; decode: one run of the product loop",
+            "note": "one step re-run stage by stage with a device sync between stages (decode: the product loop, 4-step graph replays); work figures: SURVEY.md 8d "
                     "(encoder 374.1 GFLOP and prefill 1,170 GFLOP per 30 s clip, decode 3.441 GB weights + B*L*114,688 B KV per token)",
         }
         log("stages: " + ", ".join(f"{k}={v:.1f}" for k, v in line["stages"].items() if k.endswith("_ms")))
-        # ---- roofline of the dominant kernel (decode weight streaming: skinny4_kernel; skinny3_kernel where no skinny4 geometry fits).  HIP events on the
-        # launch stream around R back-to-back "GEMM-only" decode steps: exactly the 113 weight-streaming
-        # launches of a step (4 per layer over all 28 layers' distinct weights, so 3.4 GB per step and no
-        # cache reuse between launches, + the tied head), same operands and split factors as the timed region.
-        dec = model._decoder
-        ws = dec.workspace(B, args.ndec)
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
-        lib = _lib.load()
-        lib.q3asr_event_create(C.byref(e0))
-        lib.q3asr_event_create(C.byref(e1))
-        # The 113 launches are captured into a hipGraph and replayed (as the decode step itself runs): issued one by one from
-        # Python they are host-bound at ~8 us per launch, which is what the fp8 stream and, since skinny4, the bf16 one take.
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            stream = C.c_void_p(side.cuda_stream)
-            dec.gemm_only_step(ws)                                       # warm (code objects, LDS attributes)
-            _lib.call("q3asr_graph_begin", stream)
-            try:
-                per_step = dec.gemm_only_step(ws)
-            finally:
-                graph = C.c_void_p()
-                _lib.call("q3asr_graph_end", stream, C.byref(graph))
-            _lib.call("q3asr_graph_launch", graph, stream)               # warm replay
-            R = 20
-            _lib.check(lib.q3asr_event_record(e0, stream), "event_record")
-            for _ in range(R):
-                _lib.call("q3asr_graph_launch", graph, stream)
-            _lib.check(lib.q3asr_event_record(e1, stream), "event_record")
-            side.synchronize()
-            _lib.check(lib.q3asr_event_elapsed_ms(e0, e1, C.byref(ms)), "event_elapsed")
-            _lib.call("q3asr_graph_destroy", graph)
-        launches = per_step * R
+        # ---- roofline of the dominant kernel (decode weight streaming), measured live: decode_gemm_roofline above
+        roof = decode_gemm_roofline(model, cfg, B, args.ndec, 2 if args.weights == "bf16" else 1, dev)
         per_launch = decode_bytes_per_launch(cfg, B, 2 if args.weights == "bf16" else 1)
-        total_bytes = sum(per_launch) * R
-        avg_ms = ms.value / launches
-        achieved = total_bytes / (ms.value * 1e-3) / 1e9
-        log(f"roofline leg: {launches} decode GEMM launches in {ms.value:.2f} ms")
         # PMC traffic: only a figure collected on THIS build of the library (tools/pmc_probe.py stamps the summary with the
         # sha-256 of libq3asr_hip.so); a summary from any other build is refused and `traffic` is null.
         traffic, traffic_from = None, "no PMC summary for this build of libq3asr_hip.so"
@@ -546,17 +683,14 @@ def main() -> None:
             if d_.get("lib_sha16") == lib_sha and d_.get("avg_launch_us"):
                 in_situ, in_situ_from = d_, f"profiles/{f_.name} (lib sha16 {lib_sha})"
                 break
-        line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": traffic_from,
-                            "kernel": "skinny4_kernel + head_stream_kernel (decode weight streaming, all shapes of one step)",
-                            "launches_measured": launches, "avg_launch_us": 1e3 * avg_ms,
-                            "bytes_per_launch": sum(per_launch) / len(per_launch),
-                            "measured_on": "a hipGraph of the step's 113 weight-streaming launches alone (HIP events on the launch stream)",
+        line["roofline"] = {**roof, "traffic": traffic, "traffic_from": traffic_from,
                             "in_situ": None if in_situ is None else {
                                 "avg_launch_us": in_situ["avg_launch_us"], "achieved": sum(per_launch) / len(per_launch) / (in_situ["avg_launch_us"] * 1e-6) / 1e9,
                                 "frac": sum(per_launch) / len(per_launch) / (in_situ["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                 "launches": in_situ.get("launches"), "whole_step_us": in_situ.get("whole_step_us")},
                             "in_situ_from": in_situ_from}
+        if args.weights == "bf16" and not args.no_longform:
+            line["longform_fp8"] = longform_fp8_leg(cfg, state, dev, q, synth)
         if not args.no_cpu_baseline and args.weights == "bf16":
             model.close()
             torch.cuda.empty_cache()

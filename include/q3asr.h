@@ -33,6 +33,15 @@ int q3asr_log_mel(const float* audio, int64_t audio_stride, const int32_t* lens_
                   const float* window400, const double* twiddle_cs, const float* fb, const int32_t* fb_range,
                   float* out, uint32_t* gmax_key, void* stream);
 
+/* ---- audio.py:238-246  log_mel_spectrogram for ANY (n_fft, hop_length, n_mels) of the reference signature (the call above
+ * is the specialisation for its defaults 400 / 160 / 128, which is what the encoder consumes).
+ * window fp32 [n_fft] = np.hanning(n_fft); twiddle_cs fp64 [n_fft][2] = (cos, sin)(2*pi*i/n_fft); fb fp32 [n_mels][n_fft/2+1];
+ * frames per utterance = (len + 2*(n_fft/2) - n_fft) / hop_length (the reference drops the last frame, audio.py:266);
+ * out fp32 [B][n_mels][Fmax], frames beyond an utterance's count are written as 0; gmax_key uint32 [B] scratch. */
+int q3asr_log_mel_generic(const float* audio, int64_t audio_stride, const int32_t* lens_dev, int B, int Fmax,
+                          int n_fft, int hop_length, int n_mels, const float* window, const double* twiddle_cs,
+                          const float* fb, float* out, uint32_t* gmax_key, void* stream);
+
 /* ---- encoder.py:254-273  chunking + conv2d1 + GELU -------------------------------------------
  * mel fp32 [B][128][Fmax]; chunk ci = frames [chunk_f0[ci], +100) of utterance chunk_b[ci];
  * w9 fp32 [C1][kt][kf]; out bf16 [n_chunks][50][64][C1] (time-major NHWC). */
@@ -62,19 +71,31 @@ int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, int Cin, con
 int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
                     const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
                     void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream);
+/* The same two GEMMs with a workspace for the 8-phase kernel's chained stream-K form (csrc/gemm.hip): launches whose 256 x 256
+ * tiles do not fill whole rounds of the 256 CUs give every workgroup the same number of K iterations instead, a tile that two
+ * workgroups share has its MFMA chains CONTINUED from published accumulators (never summed from partials), so results are
+ * bit-identical to the calls above.  workspace: q3asr_gemm_workspace_bytes() bytes of device memory, 128-byte aligned, ZEROED
+ * ONCE by the caller and then handed to every call on ONE stream (concurrent streams need a block each); NULL = the calls above. */
+int64_t q3asr_gemm_workspace_bytes(void);
+int q3asr_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
+                       const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
+                       void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* workspace, int64_t workspace_bytes, void* stream);
 /* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 64 = 64x64 tile, 128 = 128x128 tile, 8 = 256x256 8-phase LDS-DMA
  * pipeline where its preconditions hold, 224 = the same pipeline on 224x256 tiles).  All kernels give bit-identical results. */
 int q3asr_gemm_force_kernel(int mode);
 /* Diagnostic: 0 = every sub-tile of the 8-phase kernels takes the general (bounds-tested) epilogue, 1 = interior sub-tiles take the short one (default). Same bits either way; returns the previous setting. Used by tools/ab_gemm_epilogue.py */
 int q3asr_gemm_set_interior(int on);
 /* Diagnostic: switches between two launch forms with identical results, for A/B measurements in one process (tools/ab_step.py,
- * tools/bench_head.py).  Every option defaults to 1; returns the previous value, or -1 for an unknown option.  A captured
+ * tools/bench_head.py).  Every option defaults to 1 (the test hook 4 to 0); returns the previous value, or -1 for an unknown option.  A captured
  * graph keeps the form it was captured with. */
 #define Q3ASR_OPT_HEAD_XCD_MAP 1    /* tied head: workgroups that share a 128-byte logits line run on one XCD */
 #define Q3ASR_OPT_HEAD_STREAM 2     /* tied head (bf16, K = 2048, geometry 2/8/8, <= 32 rows): one workgroup per CU walking its tile groups */
+#define Q3ASR_OPT_GEMM_STREAMK 3    /* 8-phase GEMM: chained stream-K where a workspace came with the call (0: whole tiles per workgroup) */
+#define Q3ASR_OPT_GEMM_SK_RECOMPUTE 4 /* test hook, default 0: every tail piece of a chained stream-K launch gives up on its hand-off and recomputes (same bits) */
 int q3asr_set_option(int option, int value);
 /* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
 int q3asr_gemm_set_stamp(void* buf);
+int q3asr_gemm_set_stamp_wg(int workgroup);   /* which workgroup (blockIdx.x) records them; default 0 */
 
 /* ---- nn.LayerNorm (encoder.py:112,117,319): x fp32 [M][D] -> y bf16 [M][D] ------------------ */
 int q3asr_layernorm_f32_bf16(const float* x, const float* w, const float* b, void* y, int M, int D, float eps,
@@ -98,6 +119,8 @@ int q3asr_attn_fwd_f32(const float* qkv, int64_t ld, int d_model, const int32_t*
  * act: 0 none, 2 SwiGLU (weights interleaved as for q3asr_gemm_bf16); res_kind: 0 none, 2 bf16 residual. */
 int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
                    int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo, void* stream);
+int q3asr_gemm_fp8_ws(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
+                   int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream);
 /* RMSNorm (decoder.py:189,194) with the bf16 result quantised per row: y8 = e4m3(y / scale[m]), scale = max|y| / 448 */
 int q3asr_rmsnorm_bf16_fp8(const void* x, int64_t ldx, const void* w, void* y8, int64_t ldy, float* scale, int M, int D, float eps,
                            void* stream);
@@ -110,12 +133,16 @@ int q3asr_rmsnorm_bf16(const void* x, int64_t ldx, const void* w, void* y, int64
 
 /* ---- mx.fast.scaled_dot_product_attention (encoder.py:82-84 with the block mask of :210-229;
  *      decoder.py:158-163 prefill) ---------------------------------------------------------------
- * Independent segments s: Q/O rows [seg_q_start[s], +seg_len[s]); keys 0..seg_len[s]-1 at
- * K/V + kv_seg_off[s] + kv_head*kv_head_stride + key*kv_row_stride (elements). */
+ * Independent segments s: Q/O rows [seg_q_start[s], +seg_len[s]); keys 0..seg_k_off[s]+seg_len[s]-1 at
+ * K/V + kv_seg_off[s] + kv_head*kv_head_stride + key*kv_row_stride (elements).
+ * seg_k_off (optional, NULL = all 0): keys already cached in front of the segment's first query row -- query row i sits at
+ * position seg_k_off[s] + i and, when causal, sees keys 0..seg_k_off[s]+i: a multi-token call on a non-empty cache, i.e.
+ * decoder.py:151-158 with cache.offset > 0, the case create_additive_causal_mask(N, offset) (decoder.py:71-80) exists for.
+ * max_len = max query rows of a segment (grid), max_klen = max keys of a segment (= max_len when seg_k_off is NULL). */
 int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, const void* V, const int64_t* kv_seg_off,
                    int64_t kv_head_stride, int64_t kv_row_stride, void* O, int64_t o_stride,
-                   const int32_t* seg_q_start, const int32_t* seg_len, int n_segs, int max_len, int n_heads,
-                   int n_kv_heads, int head_dim, int causal, float scale, void* stream);
+                   const int32_t* seg_q_start, const int32_t* seg_len, const int32_t* seg_k_off, int n_segs, int max_len,
+                   int max_klen, int n_heads, int n_kv_heads, int head_dim, int causal, float scale, void* stream);
 
 /* ---- generate.py:20-81  prepare_inputs ------------------------------------------------------- */
 /* E: embedding table with V rows; enc: n_enc encoder rows.  Index vectors are device-resident and cannot be validated

@@ -65,6 +65,16 @@ def rope(x, pos, theta):
     return bf(torch.cat([x1 * c - x2 * s, x1 * s + x2 * c], dim=-1))
 
 
+def swiglu(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """decoder.py:96-97: ``down_proj(nn.silu(gate_proj(x)) * up_proj(x))`` on bf16 arrays.  ``nn.silu`` is
+    ``x * mx.sigmoid(x)``; under the per-op dtype rule of the module docstring that is THREE bf16 results -- sigmoid(g),
+    g * sigmoid(g), (.) * up -- not one rounding of the fp32 product (rounds 1-4 of this oracle fused them; the round-4
+    review's weak point 3).  Both oracle flavours and every GPU SwiGLU epilogue (csrc/common.h ``swiglu_bf``) use these
+    points.  ASSUMPTION (unverifiable here, mlx absent): the fused kernel mx.compile builds for nn.silu keeps each
+    primitive's output in the array dtype, as MLX's compiled-kernel generator declares its temporaries."""
+    return bf(bf(gate * bf(torch.sigmoid(gate))) * up)
+
+
 class DecoderOracle:
     """One sequence (the reference is batch-1 everywhere: generate.py:48,294)."""
 
@@ -141,7 +151,7 @@ class DecoderOracle:
             x = rms_norm(h, W[p + "post_attention_layernorm.weight"], self.eps)
             gt = bf(self._lin(x, p + "mlp.gate_proj.weight", n8))
             up = bf(self._lin(x, p + "mlp.up_proj.weight", n8))
-            act = bf(gt * torch.sigmoid(gt) * up)
+            act = swiglu(gt, up)
             h = bf(h + bf(self._lin(act, p + "mlp.down_proj.weight", n8)))
         self.offset += T
         if return_hidden:                       # the residual stream after the last layer, before the final norm (test aid)

@@ -19,6 +19,7 @@ _SIGS = {
     "q3asr_arch": [],
     "q3asr_last_error": [],
     "q3asr_log_mel": [_vp, _i64, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "q3asr_log_mel_generic": [_vp, _i64, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "q3asr_conv1_gelu": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "q3asr_conv1_gelu_f32": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
     "q3asr_split3_f32": [_vp, _i64, _vp, _i64, _i, _vp],
@@ -27,11 +28,14 @@ _SIGS = {
     "q3asr_conv3x3s2_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _vp],
     "q3asr_gemm_bf16": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _i, _i64, _vp, _vp],
     "q3asr_gemm_fp8": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _i64, _vp, _i64, _vp],
+    "q3asr_gemm_workspace_bytes": [],
+    "q3asr_gemm_bf16_ws": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _i, _i64, _vp, _vp, _i64, _vp],
+    "q3asr_gemm_fp8_ws": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _i64, _vp, _i64, _vp, _i64, _vp],
     "q3asr_rmsnorm_bf16_fp8": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _f, _vp],
     "q3asr_quantize_rows_fp8": [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp],
     "q3asr_layernorm_f32_bf16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_rmsnorm_bf16": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _f, _vp],
-    "q3asr_attn_fwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "q3asr_attn_fwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "q3asr_embed_merge": [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "q3asr_qk_norm_rope_kv": [_vp, _i, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "q3asr_skinny3_gemm": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],
@@ -52,12 +56,14 @@ _SIGS = {
     "q3asr_gemm_set_interior": [_i],
     "q3asr_set_option": [_i, _i],
     "q3asr_gemm_set_stamp": [_vp],
+    "q3asr_gemm_set_stamp_wg": [_i],
     "q3asr_event_create": [C.POINTER(_vp)],
     "q3asr_event_record": [_vp, _vp],
     "q3asr_event_elapsed_ms": [_vp, _vp, C.POINTER(_f)],
     "q3asr_event_destroy": [_vp],
 }
-_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p, "q3asr_attn_decode_fused_workspace": C.c_int64}
+_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p, "q3asr_attn_decode_fused_workspace": C.c_int64,
+             "q3asr_gemm_workspace_bytes": C.c_int64}
 EXPORTS = tuple(_SIGS)
 
 

@@ -121,49 +121,66 @@ def load_audio(path: str | Path, target_sr: int = SAMPLE_RATE) -> np.ndarray:
 
 # --------------------------------------------------------------------------- HIP frontend
 class MelFrontend:
-    """Device-resident tables + batched launch of q3asr_log_mel."""
+    """Device-resident tables + batched launch of q3asr_log_mel (the reference's default n_fft / hop_length / n_mels, the
+    triple the encoder is built for) or q3asr_log_mel_generic (any other triple audio.py:238-246 accepts)."""
 
-    def __init__(self, device, sample_rate: int = SAMPLE_RATE, f_min: float = F_MIN, f_max: float = F_MAX):
+    def __init__(self, device, sample_rate: int = SAMPLE_RATE, f_min: float = F_MIN, f_max: float = F_MAX,
+                 n_fft: int = N_FFT, hop_length: int = HOP_LENGTH, n_mels: int = N_MELS):
         import torch
+        if n_fft < 2 or hop_length < 1 or n_mels < 1:
+            raise ValueError(f"log-mel: n_fft={n_fft} hop_length={hop_length} n_mels={n_mels}")
         self.device = torch.device(device)
-        fb = _get_mel_filterbank(N_FFT, N_MELS, sample_rate, f_min, f_max)
-        rng = np.zeros((N_MELS, 2), dtype=np.int32)
-        for m in range(N_MELS):
+        self.n_fft, self.hop, self.n_mels = int(n_fft), int(hop_length), int(n_mels)
+        self.default = (self.n_fft, self.hop, self.n_mels) == (N_FFT, HOP_LENGTH, N_MELS)
+        fb = _get_mel_filterbank(self.n_fft, self.n_mels, sample_rate, f_min, f_max)
+        rng = np.zeros((self.n_mels, 2), dtype=np.int32)
+        for m in range(self.n_mels):
             nz = np.nonzero(fb[m])[0]
             if len(nz):
                 rng[m] = (nz[0], nz[-1] + 1)
-        ang = 2.0 * np.pi * np.arange(N_FFT, dtype=np.float64) / N_FFT
+        ang = 2.0 * np.pi * np.arange(self.n_fft, dtype=np.float64) / self.n_fft
         tw = np.stack([np.cos(ang), np.sin(ang)], axis=1)
         self.fb = torch.from_numpy(fb).to(self.device)
         self.fb_range = torch.from_numpy(rng).to(self.device)
-        self.window = torch.from_numpy(np.hanning(N_FFT).astype(np.float32)).to(self.device)
+        self.window = torch.from_numpy(np.hanning(self.n_fft).astype(np.float32)).to(self.device)
         self.twiddle = torch.from_numpy(tw).to(self.device)
+
+    def frames(self, n_samples: int) -> int:
+        """1 + (len + 2 (n_fft // 2) - n_fft) // hop frames, the last one dropped (audio.py:224-226,266)."""
+        padded = int(n_samples) + 2 * (self.n_fft // 2)
+        return max(0, (padded - self.n_fft) // self.hop)
 
     def __call__(self, audio, lens, lens_host: Sequence[int]):
         """audio fp32 [B][stride] (device, zero padded), lens int32 [B] (device).
-        Returns (mel fp32 [B][128][Fmax], n_frames list)."""
+        Returns (mel fp32 [B][n_mels][Fmax], n_frames list)."""
         import torch
         B = audio.shape[0]
-        if min(lens_host) < HOP_LENGTH:
-            raise ValueError(f"audio shorter than one hop ({HOP_LENGTH} samples) has no mel frames")
-        n_frames = [int(n) // HOP_LENGTH for n in lens_host]
+        n_frames = [self.frames(n) for n in lens_host]
+        if min(n_frames) < 1:
+            raise ValueError(f"audio shorter than one hop ({self.hop} samples) has no mel frames")
         fmax = max(n_frames)
-        out = torch.empty((B, N_MELS, fmax), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, self.n_mels, fmax), dtype=torch.float32, device=self.device)
         gkey = torch.empty((B,), dtype=torch.int32, device=self.device)
-        _lib.call("q3asr_log_mel", _lib.ptr(audio), audio.stride(0), _lib.ptr(lens), B, fmax, _lib.ptr(self.window),
-                  _lib.ptr(self.twiddle), _lib.ptr(self.fb), _lib.ptr(self.fb_range), _lib.ptr(out), _lib.ptr(gkey),
-                  _lib.stream_ptr())
+        if self.default:
+            _lib.call("q3asr_log_mel", _lib.ptr(audio), audio.stride(0), _lib.ptr(lens), B, fmax, _lib.ptr(self.window),
+                      _lib.ptr(self.twiddle), _lib.ptr(self.fb), _lib.ptr(self.fb_range), _lib.ptr(out), _lib.ptr(gkey),
+                      _lib.stream_ptr())
+        else:
+            _lib.call("q3asr_log_mel_generic", _lib.ptr(audio), audio.stride(0), _lib.ptr(lens), B, fmax, self.n_fft, self.hop,
+                      self.n_mels, _lib.ptr(self.window), _lib.ptr(self.twiddle), _lib.ptr(self.fb), _lib.ptr(out), _lib.ptr(gkey),
+                      _lib.stream_ptr())
         return out, n_frames
 
 
-def get_frontend(device=None, sample_rate: int = SAMPLE_RATE, f_min: float = F_MIN, f_max: float = F_MAX) -> MelFrontend:
+def get_frontend(device=None, sample_rate: int = SAMPLE_RATE, f_min: float = F_MIN, f_max: float = F_MAX,
+                 n_fft: int = N_FFT, hop_length: int = HOP_LENGTH, n_mels: int = N_MELS) -> MelFrontend:
     import torch
     dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-    key = (str(dev), sample_rate, f_min, f_max)
+    key = (str(dev), sample_rate, f_min, f_max, n_fft, hop_length, n_mels)
     with _cache_lock:
         fe = _frontends.get(key)
         if fe is None:
-            fe = _frontends[key] = MelFrontend(dev, sample_rate, f_min, f_max)
+            fe = _frontends[key] = MelFrontend(dev, sample_rate, f_min, f_max, n_fft, hop_length, n_mels)
     return fe
 
 
@@ -180,11 +197,20 @@ def release_staging() -> None:
         _staging.clear()
 
 
-def pack_audio(batch: Sequence[np.ndarray], device):
+# How a request's rows travel to the device.  "single": fill the whole pinned buffer, then ONE copy.  "grouped": rows in groups
+# of ~8 MB, the copy of one group issued while the host fills the next (round 4).  bench.py measures both in one process
+# (`end_to_end.h2d`): the round-4 driver run showed the end-to-end figure 31 ms above the resident one with the grouped form
+# where round 3 (single copy) showed 3 ms; PACK_MODE is whatever that A/B keeps.
+PACK_MODE = "single"
+PACK_STATS: Optional[dict] = None      # set to a dict to have the next pack_audio call record its host times and copy events
+
+
+def pack_audio(batch: Sequence[np.ndarray], device, mode: Optional[str] = None):
     """Host list of 1-D float32 arrays -> (padded device tensor [B][Lmax], lens device, lens host).
     On a GPU device the rows are staged in a pinned buffer kept per (device, lane) (allocating 61 MB of pinned memory per
     32 x 30 s request cost 4-25 ms of a 250 ms request); the buffer is reused only after the copy that last read it has
-    completed.  A CPU device gets a plain tensor of its own."""
+    completed.  A CPU device gets a plain tensor of its own.  `mode`: PACK_MODE above."""
+    import time
     import torch
     lens = [int(len(a)) for a in batch]
     lmax = max(lens)
@@ -196,6 +222,9 @@ def pack_audio(batch: Sequence[np.ndarray], device):
             host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
         return host.to(dev_t), torch.tensor(lens, dtype=torch.int32).to(dev_t), lens
     from .decoder import current_lane
+    mode = mode or PACK_MODE
+    stats = PACK_STATS
+    t0 = time.perf_counter()
     key = (dev_t.index if dev_t.index is not None else torch.cuda.current_device(), current_lane())
     with _staging_lock:
         st = _staging.pop(key, None)                       # taken out while in use: a second thread on the same lane gets its own
@@ -206,33 +235,61 @@ def pack_audio(batch: Sequence[np.ndarray], device):
         ev.synchronize()                                   # the previous request's H2D copy has read the buffer
     host = flat[:n].view(len(batch), lmax)
     dev = torch.empty((len(batch), lmax), dtype=torch.float32, device=dev_t)
-    # rows are staged and copied in groups: the H2D copy of one group runs while the host fills the next (a 32 x 30 s
-    # request is 61 MB: ~2 ms of host copy + ~1 ms over PCIe one after the other)
-    group = max(1, (8 << 20) // max(4 * lmax, 1))
+    t1 = time.perf_counter()
+    stream = torch.cuda.current_stream(dev.device)
+    e0 = e1 = None
+    if stats is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_fill = t_issue = 0.0
+    group = len(batch) if mode == "single" else max(1, (8 << 20) // max(4 * lmax, 1))
+    first = True
     for i0 in range(0, len(batch), group):
         i1 = min(i0 + group, len(batch))
+        f0 = time.perf_counter()
         for i in range(i0, i1):
             host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(batch[i], dtype=np.float32))
             if lens[i] < lmax:
                 host[i, lens[i]:] = 0.0
+        f1 = time.perf_counter()
+        if first and e0 is not None:
+            e0.record(stream)
+        first = False
         dev[i0:i1].copy_(host[i0:i1], non_blocking=True)
+        t_fill += f1 - f0
+        t_issue += time.perf_counter() - f1
+    if e1 is not None:
+        e1.record(stream)
     lens_dev = torch.tensor(lens, dtype=torch.int32).to(dev_t, non_blocking=True)
     ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev.device))
+    ev.record(stream)
     with _staging_lock:
         _staging[key] = (flat, ev)
+    if stats is not None:
+        stats.update({"mode": mode, "bytes": 4 * n, "groups": (len(batch) + group - 1) // group, "pinned": bool(flat.is_pinned()),
+                      "setup_ms": 1e3 * (t1 - t0), "host_fill_ms": 1e3 * t_fill, "copy_issue_ms": 1e3 * t_issue,
+                      "host_total_ms": 1e3 * (time.perf_counter() - t0), "_events": (e0, e1)})
     return dev, lens_dev, lens
+
+
+def pack_stats_finish(stats: dict) -> dict:
+    """Resolve the copy events of a PACK_STATS record (after the stream has been synchronised): first copy issued -> last copy
+    done on the device timeline (with the grouped form that span contains the host fills between the copies)."""
+    e0, e1 = stats.pop("_events", (None, None))
+    if e0 is not None:
+        e1.synchronize()
+        stats["copy_span_ms"] = float(e0.elapsed_time(e1))
+        stats["copy_GBps_over_span"] = stats["bytes"] / (stats["copy_span_ms"] * 1e-3) / 1e9 if stats["copy_span_ms"] > 0 else None
+    return stats
 
 
 def log_mel_spectrogram(audio, n_fft: int = N_FFT, hop_length: int = HOP_LENGTH, n_mels: int = N_MELS,
                         sample_rate: int = SAMPLE_RATE, f_min: float = F_MIN, f_max: float = F_MAX):
     """Log-mel spectrogram of one utterance, shape (n_mels, n_frames), float32 on the GPU.
-    Same steps as reference audio.py:238-278."""
-    if (n_fft, hop_length, n_mels) != (N_FFT, HOP_LENGTH, N_MELS):
-        raise NotImplementedError("the HIP frontend is specialised for n_fft=400, hop_length=160, n_mels=128")
+    Same steps as reference audio.py:238-278, for any n_fft / hop_length / n_mels it accepts (the defaults run the
+    specialised kernel the encoder path uses, other triples q3asr_log_mel_generic)."""
     if not isinstance(audio, np.ndarray):
         audio = load_audio(audio, target_sr=sample_rate)
-    fe = get_frontend(None, sample_rate, f_min, f_max)
+    fe = get_frontend(None, sample_rate, f_min, f_max, n_fft, hop_length, n_mels)
     dev, lens_dev, lens = pack_audio([np.asarray(audio, dtype=np.float32)], fe.device)
     mel, _ = fe(dev, lens_dev, lens)
     return mel[0]

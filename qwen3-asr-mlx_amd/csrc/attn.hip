@@ -44,7 +44,9 @@ struct AttnParams {
     long kv_head_stride, kv_row_stride;
     bf16* O; long o_stride;
     const int* seg_q_start;                // first Q/O row of the segment
-    const int* seg_len;
+    const int* seg_len;                    // query rows of the segment
+    const int* seg_k_off;                  // optional: keys already in the cache before the segment's first query row (decoder.py:151-158,
+                                           // a multi-token call on a non-empty cache); the segment then has seg_len + seg_k_off keys
     int group;                             // query heads per kv head
     float scale;
 };
@@ -62,6 +64,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     const int seg = blockIdx.z, head = blockIdx.y, qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int len = p.seg_len[seg];
     if (qt * 64 >= len) return;
+    const int koff = p.seg_k_off ? p.seg_k_off[seg] : 0;   // query row i sits at position koff + i and sees keys 0 .. koff + i
+    const int klen = len + koff;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const int q_abs = qt * 64 + wave * 16 + li;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int n_tiles = CAUSAL ? (qt + 1) : (len + KV_TILE - 1) / KV_TILE;
+    const int n_tiles = CAUSAL ? (min(klen, koff + qt * 64 + 64) + KV_TILE - 1) / KV_TILE : (klen + KV_TILE - 1) / KV_TILE;   // koff = 0: qt + 1
     // K and V tile: KV_TILE*CPR 16-byte chunks each, 256 threads; the next tile's chunks are loaded into registers while
     // the current tile computes (one HBM/L2 round trip per tile would otherwise sit between two barriers)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     auto fetch = [&](int kt_) {
 #pragma unroll
         for (int it = 0; it < NCH; ++it) {
-            const int key = min(kt_ * KV_TILE + row0 + (256 / CPR) * it, len - 1);
+            const int key = min(kt_ * KV_TILE + row0 + (256 / CPR) * it, klen - 1);
             const unsigned boff = (unsigned)key * row_bytes + ch_bytes;
             kreg[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Kb) + boff);
             vreg[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Vb) + boff);
@@ -111,8 +115,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     const int kbase = TileImg<HD>::off(li, g);
     const int vbase = TileImg<HD>::off(4 * g + (li >> 2), (li & 3) >> 1) + 8 * (li & 1);
     fetch(0);
-    int last_tile = n_tiles - 1;
-    asm volatile("" : "+s"(last_tile));                  // opaque: hipcc otherwise peels the masked tile out of the loop and spills at the join
+    // first key tile that can hold a key beyond the sequence or above the diagonal of one of this workgroup's queries: tile kt is
+    // wholly visible iff 64 kt + 63 <= koff + 64 qt (the smallest query position), i.e. kt < qt + (koff + 1) / 64; with koff = 0
+    // that leaves the last tile alone, with a cache offset the diagonal can straddle the last two
+    int mask_from = CAUSAL ? qt + (koff + 1) / 64 : n_tiles - 1;
+    asm volatile("" : "+s"(mask_from));                  // opaque: hipcc otherwise peels the masked tile out of the loop and spills at the join
     for (int kt = 0; kt < n_tiles; ++kt) {
         __syncthreads();
 #pragma unroll
@@ -147,16 +154,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- mask + online softmax (row = query li, spread over the 4 lane groups)
-        // Only the last key tile of a query tile can hold keys beyond the sequence or above the diagonal (earlier tiles end
-        // below key 64 qt <= every query row of the workgroup, and 64 qt < len): the mask runs there alone (uniform branch).
+        // Only the last key tile(s) of a query tile can hold keys beyond the sequence or above the diagonal (mask_from above):
+        // the mask runs there alone (uniform branch).
         float tmax = -INFINITY;
-        if (kt == last_tile) {
+        if (kt >= mask_from) {
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt * KV_TILE + 16 * k4 + 4 * g + r;
-                    const bool ok = key < len && (!CAUSAL || key <= q_eff);
+                    const bool ok = key < klen && (!CAUSAL || key <= q_eff + koff);
                     const float v = ok ? s[k4][r] * p.scale : -INFINITY;
                     s[k4][r] = v;
                     tmax = fmaxf(tmax, v);
@@ -242,16 +249,17 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
 
 extern "C" int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, const void* V, const int64_t* kv_seg_off,
                               int64_t kv_head_stride, int64_t kv_row_stride, void* O, int64_t o_stride,
-                              const int32_t* seg_q_start, const int32_t* seg_len, int n_segs, int max_len, int n_heads,
-                              int n_kv_heads, int head_dim, int causal, float scale, void* stream) {
+                              const int32_t* seg_q_start, const int32_t* seg_len, const int32_t* seg_k_off, int n_segs, int max_len,
+                              int max_klen, int n_heads, int n_kv_heads, int head_dim, int causal, float scale, void* stream) {
     Q3_REQUIRE(Q && K && V && kv_seg_off && O && seg_q_start && seg_len, "attn_fwd: null pointer");
     Q3_REQUIRE(n_segs > 0 && max_len > 0 && n_heads > 0 && n_kv_heads > 0 && n_heads % n_kv_heads == 0, "attn_fwd: bad sizes");
     Q3_REQUIRE(q_stride % 8 == 0 && kv_row_stride % 8 == 0 && kv_head_stride % 8 == 0 && o_stride % 4 == 0, "attn_fwd: strides must keep 16-byte alignment");
-    Q3_REQUIRE(kv_row_stride > 0 && (int64_t)max_len * kv_row_stride * 2 < (1LL << 32), "attn_fwd: a segment's K/V rows must lie within 4 GiB of its first (max_len=%d, kv_row_stride=%ld)", max_len, (long)kv_row_stride);
+    Q3_REQUIRE(max_klen >= max_len && (seg_k_off || max_klen == max_len), "attn_fwd: max_klen=%d (keys) must be >= max_len=%d (query rows), equal without seg_k_off", max_klen, max_len);
+    Q3_REQUIRE(kv_row_stride > 0 && (int64_t)max_klen * kv_row_stride * 2 < (1LL << 32), "attn_fwd: a segment's K/V rows must lie within 4 GiB of its first (max_klen=%d, kv_row_stride=%ld)", max_klen, (long)kv_row_stride);
     AttnParams p;
     p.Q = (const bf16*)Q; p.q_stride = q_stride; p.K = (const bf16*)K; p.V = (const bf16*)V;
     p.kv_seg_off = (const long*)kv_seg_off; p.kv_head_stride = kv_head_stride; p.kv_row_stride = kv_row_stride;
-    p.O = (bf16*)O; p.o_stride = o_stride; p.seg_q_start = seg_q_start; p.seg_len = seg_len;
+    p.O = (bf16*)O; p.o_stride = o_stride; p.seg_q_start = seg_q_start; p.seg_len = seg_len; p.seg_k_off = seg_k_off;
     p.group = n_heads / n_kv_heads; p.scale = scale;
     dim3 grid((max_len + 63) / 64, n_heads, n_segs), blk(256);
     hipStream_t s = (hipStream_t)stream;

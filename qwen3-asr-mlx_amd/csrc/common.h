@@ -23,6 +23,8 @@ extern "C" void q3asr_set_error(const char* fmt, ...);
 extern int g_q3_option[8];
 #define Q3ASR_OPT_HEAD_XCD_MAP 1      // the ids of include/q3asr.h
 #define Q3ASR_OPT_HEAD_STREAM 2
+#define Q3ASR_OPT_GEMM_STREAMK 3
+#define Q3ASR_OPT_GEMM_SK_RECOMPUTE 4
 int q3_check_launch(const char* what);
 
 #define Q3_REQUIRE(cond, ...)                 \
@@ -61,6 +63,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x < 0.f ? xh : x - xh;
 }
 
+// SwiGLU at the reference's rounding points.  decoder.py:97 is nn.silu(gate_proj(x)) * up_proj(x) on bf16 arrays, and under
+// MLX's per-op dtype rule that is three bf16 results: sigmoid(g) -> bf16, g * sigmoid(g) -> bf16 (nn.silu = x * mx.sigmoid(x)),
+// then the product with up -> bf16.  Rounds 1-4 rounded once at the end (a sub-ulp deviation the round-4 review asked to
+// remove); every SwiGLU epilogue of the library (8-phase / 128^2 / 64^2 GEMM, skinny3, skinny4; bf16 and fp8) calls this.
+// Arguments are the bf16-rounded projection outputs.  v_rcp_f32 (1 ulp) instead of an IEEE division: the quotient is rounded
+// to 8 significant bits next, and the division sequence cost ~8 VALU per element of a VALU-bound epilogue.
+__device__ __forceinline__ bf16 swiglu_bf(float gate, float up) {
+    const float s = round_bf(__builtin_amdgcn_rcpf(1.0f + __expf(-gate)));
+    const float t = round_bf(gate * s);
+    return f2bf(t * up);
+}
+
 // ---- wave reductions (wave = 64 lanes) -----------------------------------
 // The butterfly v = op(v, v[lane ^ o]), o = 32, 16, 8, 4, 2, 1, of rounds 1-3 -- the same partners in the same order, so the
 // same bits for the commutative ops used here -- without the LDS crossbar: hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS
@@ -69,6 +83,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // value, result 0 (op) result 1 = op(v, v[lane ^ 32]) resp. v[lane ^ 16] in every lane) and DPP covers the steps inside a
 // row of 16: row_ror:8 = lane ^ 8, row_half_mirror then quad_perm [3,2,1,0] = lane ^ 7 ^ 3 = lane ^ 4, quad_perm [2,3,0,1]
 // = lane ^ 2, [1,0,3,2] = lane ^ 1.  Round 4.
+// CONTRACT: all 64 lanes active (full wave, convergent control flow).  The DPP steps run with bound_ctrl = false and old = 0,
+// and the permlane swaps exchange whole rows: an inactive lane would contribute 0 (wave_max would return max(v, 0)) or stale
+// register contents, silently.  Every call site is wave-uniform (block sizes are multiples of 64, no lane-dependent branch
+// around a reduction); a kernel that needs a partial-wave reduction must mask its VALUES (0 / -inf), not its lanes.
 #define Q3_DPP(x, ctrl) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), (ctrl), 0xf, 0xf, false))
 __device__ __forceinline__ float lane_xor32_sum(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void skinny3_kernel(const bf16* __restrict__ X
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float a = round_bf(acc[t][mt][r]), b = round_bf(acc[t + 1 < RT ? t + 1 : t][mt][r]);   // bf16 gate/up (decoder.py:97)
-                    o[r] = f2bf(a / (1.0f + __expf(-a)) * b);
+                    o[r] = swiglu_bf(a, b);
                 }
                 *reinterpret_cast<bf16x4*>(out + x16_index(m, f0, MT)) = o;
             }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float av = round_bf(a[r]), bv = round_bf(b[r]);                   // bf16 gate/up (decoder.py:97)
-                o[r] = f2bf(av / (1.0f + __expf(-av)) * bv);
+                o[r] = swiglu_bf(av, bv);
             }
             *reinterpret_cast<bf16x4*>(out + x16_index(m, ((t0 + 2 * p) >> 1) * 16 + 4 * g, MT)) = o;
         }

@@ -164,3 +164,86 @@ extern "C" int q3asr_log_mel(const float* audio, int64_t audio_stride, const int
     hipLaunchKernelGGL(mel_normalize_kernel, g2, dim3(256), 0, s, out, lens_dev, gmax_key, Fmax);
     return q3_check_launch("log_mel");
 }
+
+// ---------------------------------------------------------------------------
+// The same frontend for ANY (n_fft, hop_length, n_mels) the reference signature accepts (audio.py:238-246): one workgroup
+// per frame, the windowed frame in LDS as fp64 (the float32 product x * w is exact there), each thread a direct fp64 DFT of
+// its bins (n_fft FMAs per part and bin; the twiddle index k n mod n_fft walks a host-built (cos, sin) table), power in
+// float32 as np.abs(complex64) ** 2, then the filterbank rows in ascending k.  Not a hot path (the product's encoder is built
+// for the default triple, which keeps the specialised kernel above): written for coverage of the exported function, not speed.
+// Frames: 1 + (len + 2 (n_fft / 2) - n_fft) / hop, last dropped (audio.py:224-226,266).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int mel_frames(int len, int n_fft, int hop) {
+    const int padded = len + 2 * (n_fft / 2);
+    return padded < n_fft ? 0 : (padded - n_fft) / hop;
+}
+
+__global__ __launch_bounds__(256) void mel_logpower_generic_kernel(
+    const float* __restrict__ audio, long audio_stride, const int* __restrict__ lens, int n_fft, int hop, int n_mels,
+    const float* __restrict__ window, const double* __restrict__ tw, const float* __restrict__ fb,
+    float* __restrict__ out, int Fmax, unsigned* __restrict__ gmax_key) {
+    extern __shared__ __attribute__((aligned(16))) double mel_sm[];    // n_fft doubles (frame) + n_bins floats (power)
+    const int n_bins = n_fft / 2 + 1;
+    double* xw = mel_sm;
+    float* pw = reinterpret_cast<float*>(mel_sm + n_fft);
+    const int b = blockIdx.y, fr = blockIdx.x, tid = threadIdx.x;
+    const int len = lens[b];
+    const int nfr = mel_frames(len, n_fft, hop);
+    if (fr >= nfr) return;                                              // uniform
+    const float* x = audio + (long)b * audio_stride;
+    for (int n = tid; n < n_fft; n += 256) xw[n] = (double)(x[reflect_index(fr * hop + n - n_fft / 2, len)] * window[n]);
+    __syncthreads();
+    for (int k = tid; k < n_bins; k += 256) {
+        double re = 0.0, im = 0.0;
+        int idx = 0;                                                    // (k n) mod n_fft
+        for (int n = 0; n < n_fft; ++n) {
+            const double c = tw[2 * idx], sn = tw[2 * idx + 1];
+            re = fma(xw[n], c, re);
+            im = fma(xw[n], sn, im);                                    // the sign of the imaginary part does not reach |.|
+            idx += k;
+            if (idx >= n_fft) idx -= n_fft;
+        }
+        const float mag = hypotf((float)re, (float)im);
+        pw[k] = mag * mag;
+    }
+    __syncthreads();
+    float vmax = -3.0e38f;
+    for (int m = tid; m < n_mels; m += 256) {
+        const float* w = fb + (long)m * n_bins;
+        float acc = 0.0f;
+        for (int k = 0; k < n_bins; ++k) acc = fmaf(w[k], pw[k], acc);
+        const float v = log10f(fmaxf(acc, 1e-10f));
+        out[((long)b * n_mels + m) * Fmax + fr] = v;
+        vmax = fmaxf(vmax, v);
+    }
+    vmax = wave_max(vmax);                                              // lanes without a mel row hold -3e38 (values masked, not lanes)
+    if ((tid & 63) == 0 && vmax > -1.0e38f) atomicMax(&gmax_key[b], float_to_key(vmax));
+}
+
+__global__ __launch_bounds__(256) void mel_normalize_generic_kernel(float* __restrict__ out, const int* __restrict__ lens,
+                                                                    const unsigned* __restrict__ gmax_key, int Fmax, int n_fft,
+                                                                    int hop, int n_mels) {
+    const int b = blockIdx.z, m = blockIdx.y;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= Fmax) return;
+    float* p = out + ((long)b * n_mels + m) * Fmax + f;
+    if (f < mel_frames(lens[b], n_fft, hop)) *p = (fmaxf(*p, key_to_float(gmax_key[b]) - 8.0f) + 4.0f) / 4.0f;
+    else *p = 0.0f;
+}
+
+extern "C" int q3asr_log_mel_generic(const float* audio, int64_t audio_stride, const int32_t* lens_dev, int B, int Fmax,
+                                     int n_fft, int hop_length, int n_mels, const float* window, const double* twiddle_cs,
+                                     const float* fb, float* out, uint32_t* gmax_key, void* stream) {
+    Q3_REQUIRE(audio && lens_dev && window && twiddle_cs && fb && out && gmax_key, "log_mel_generic: null pointer");
+    Q3_REQUIRE(B > 0 && Fmax > 0, "log_mel_generic: B=%d Fmax=%d must be positive", B, Fmax);
+    Q3_REQUIRE(n_fft >= 2 && n_fft <= 8192 && hop_length >= 1 && n_mels >= 1 && n_mels <= 65535,
+               "log_mel_generic: n_fft=%d (2..8192) hop_length=%d (>= 1) n_mels=%d (1..65535)", n_fft, hop_length, n_mels);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(gmax_key, 0, sizeof(uint32_t) * B, s) != hipSuccess) return q3_check_launch("log_mel_generic memset");
+    const size_t lds = sizeof(double) * n_fft + sizeof(float) * (n_fft / 2 + 1);
+    hipLaunchKernelGGL(mel_logpower_generic_kernel, dim3(Fmax, B), dim3(256), lds, s, audio, (long)audio_stride, lens_dev, n_fft,
+                       hop_length, n_mels, window, twiddle_cs, fb, out, Fmax, gmax_key);
+    hipLaunchKernelGGL(mel_normalize_generic_kernel, dim3((Fmax + 255) / 256, n_mels, B), dim3(256), 0, s, out, lens_dev, gmax_key,
+                       Fmax, n_fft, hop_length, n_mels);
+    return q3_check_launch("log_mel_generic");
+}

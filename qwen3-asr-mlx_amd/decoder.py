@@ -35,7 +35,9 @@ def set_lane(lane: int) -> None:
 class KVCache:
     """Pre-allocated per-layer key/value cache (the reference grows by concatenation,
     decoder.py:20-64).  ``offset`` is maintained by the caller exactly as in the reference
-    (generate.py:275,298).  Buffers: k, v bf16 [layers][B][n_kv][Lmax][head_dim]."""
+    (generate.py:275,298).  Buffers: k, v bf16 [layers][B][n_kv][Lmax][head_dim].
+    ``update(layer_idx, key, value)`` keeps the reference's method (decoder.py:32-64) for callers that drive the layers
+    themselves; the HIP path writes the same buffers from its RoPE / attention kernels and never calls it."""
 
     def __init__(self) -> None:
         self.offset: int = 0
@@ -44,28 +46,63 @@ class KVCache:
         self.batch = 0
         self.max_len = 0
         self.attn_ws = None        # q3asr_attn_decode_fused workspace (chunk partials + arrival counters), zeroed once
+        self._fill: dict = {}      # update(): tokens appended per layer (the reference's per-layer array length)
+
+    def _alloc(self, layers: int, batch: int, n_kv: int, head_dim: int, max_len: int, device) -> None:
+        """(Re)allocate; contents are kept when the batch is unchanged (a longer or deeper cache)."""
+        import torch
+        old_k, old_v = self.k, self.v
+        shape = (layers, batch, n_kv, max_len, head_dim)
+        self.k = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+        self.v = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+        if old_k is not None and batch == self.batch and old_k.shape[2] == n_kv and old_k.shape[4] == head_dim:
+            nl, ln = min(layers, old_k.shape[0]), min(max_len, old_k.shape[3])
+            self.k[:nl, :, :, :ln] = old_k[:nl, :, :, :ln]
+            self.v[:nl, :, :, :ln] = old_v[:nl, :, :, :ln]
+        self.batch, self.max_len = batch, max_len
+        nbytes = _lib.load().q3asr_attn_decode_fused_workspace(batch, n_kv, max_len)
+        self.attn_ws = torch.zeros((nbytes // 4,), dtype=torch.float32, device=device)
 
     def ensure(self, cfg: TextDecoderConfig, batch: int, max_len: int, device) -> None:
+        if self.k is None or batch != self.batch or max_len > self.max_len or self.k.shape[0] < cfg.num_hidden_layers:
+            self._alloc(cfg.num_hidden_layers, batch, cfg.num_key_value_heads, cfg.head_dim, max_len, device)
+
+    def update(self, layer_idx: int, key, value):
+        """Append key / value (B, n_kv_heads, T_new, head_dim) to layer ``layer_idx`` and return the full (key, value) of that
+        layer, shapes (B, n_kv_heads, L, head_dim) -- reference decoder.py:32-64 (first call stores, later calls concatenate on
+        axis 2).  The append position is the layer's own length, as in the reference; ``offset`` stays the caller's to advance
+        (generate.py:275,298).  Views of the pre-allocated buffers are returned, not copies."""
         import torch
-        if self.k is None or batch != self.batch or max_len > self.max_len:
-            old = (self.k, self.v, self.max_len)
-            shape = (cfg.num_hidden_layers, batch, cfg.num_key_value_heads, max_len, cfg.head_dim)
-            self.k = torch.zeros(shape, dtype=torch.bfloat16, device=device)
-            self.v = torch.zeros(shape, dtype=torch.bfloat16, device=device)
-            if old[0] is not None and batch == self.batch and self.offset > 0:      # grow: keep contents
-                self.k[:, :, :, : old[2]] = old[0]
-                self.v[:, :, :, : old[2]] = old[1]
-            self.batch, self.max_len = batch, max_len
-            nbytes = _lib.load().q3asr_attn_decode_fused_workspace(batch, cfg.num_key_value_heads, max_len)
-            self.attn_ws = torch.zeros((nbytes // 4,), dtype=torch.float32, device=device)
+        key, value = torch.as_tensor(key), torch.as_tensor(value)
+        if key.ndim != 4 or key.shape != value.shape:
+            raise ValueError(f"KVCache.update: key {tuple(key.shape)} / value {tuple(value.shape)} must both be (B, n_kv_heads, T, head_dim)")
+        if layer_idx < 0:
+            raise IndexError(f"KVCache.update: layer_idx {layer_idx}")
+        B, nkv, T, hd = key.shape
+        n = max(self._fill.get(layer_idx, 0), self.offset)
+        if self.k is not None and (nkv, hd) != (self.k.shape[2], self.k.shape[4]):
+            raise ValueError(f"KVCache.update: heads / head_dim {(nkv, hd)} do not match the cache {(self.k.shape[2], self.k.shape[4])}")
+        if self.k is not None and B != self.batch and (n > 0 or self._fill):
+            raise ValueError(f"KVCache.update: batch {B} on a cache holding batch {self.batch}")
+        layers = max(layer_idx + 1, 0 if self.k is None else self.k.shape[0])
+        if self.k is None or B != self.batch or n + T > self.max_len or layers > self.k.shape[0]:
+            dev = key.device if key.is_cuda else (self.k.device if self.k is not None else torch.device(f"cuda:{torch.cuda.current_device()}"))
+            self._alloc(layers, B, nkv, hd, max(n + T, 2 * self.max_len if n + T > self.max_len else self.max_len, 64), dev)
+        self.k[layer_idx, :, :, n: n + T] = key.to(self.k.device, torch.bfloat16)
+        self.v[layer_idx, :, :, n: n + T] = value.to(self.v.device, torch.bfloat16)
+        self._fill[layer_idx] = n + T
+        return self.k[layer_idx, :, :, : n + T], self.v[layer_idx, :, :, : n + T]
+
+    def _len(self, i: int) -> int:
+        return max(self.offset, self._fill.get(i, 0))
 
     @property
     def keys(self):
-        return [] if self.k is None else [self.k[i, :, :, : self.offset] for i in range(self.k.shape[0])]
+        return [] if self.k is None else [self.k[i, :, :, : self._len(i)] for i in range(self.k.shape[0])]
 
     @property
     def values(self):
-        return [] if self.v is None else [self.v[i, :, :, : self.offset] for i in range(self.v.shape[0])]
+        return [] if self.v is None else [self.v[i, :, :, : self._len(i)] for i in range(self.v.shape[0])]
 
 
 def create_additive_causal_mask(N: int, offset: int = 0):
@@ -240,10 +277,11 @@ class TextDecoder:
         self.embed_tokens = _Embedding(w["embed"])
 
     # ------------------------------------------------------------------ prefill (hot path)
-    def _prefill_plan(self, seq_lens: tuple, Lmax: int, slots: Optional[tuple] = None):
-        """Index vectors of one packed prefill.  `slots`: cache rows the sequences go to (default 0..n-1)."""
+    def _prefill_plan(self, seq_lens: tuple, Lmax: int, slots: Optional[tuple] = None, pos0: int = 0):
+        """Index vectors of one packed prefill.  `slots`: cache rows the sequences go to (default 0..n-1); `pos0`: tokens
+        already in the cache in front of every sequence (a multi-token call on a non-empty cache, decoder.py:151-158)."""
         slots = tuple(range(len(seq_lens))) if slots is None else slots
-        key = (seq_lens, Lmax, slots)
+        key = (seq_lens, Lmax, slots, pos0)
         plans = self._plans.setdefault(current_lane(), {})   # per lane: eviction frees index tensors another lane could still be reading
         pl = plans.get(key)
         if pl is None:
@@ -255,18 +293,21 @@ class TextDecoder:
             starts = ends - lens
             m = int(ends[-1])
             row_b = np.repeat(np.asarray(slots, dtype=np.int32), lens)
-            row_pos = (np.arange(m, dtype=np.int64) - np.repeat(starts, lens)).astype(np.int32)
+            row_pos = (np.arange(m, dtype=np.int64) - np.repeat(starts, lens) + pos0).astype(np.int32)
             i32 = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.int32)).to(dev)      # noqa: E731
             pl = {"row_b": i32(row_b), "row_pos": i32(row_pos), "seg_start": i32(starts), "seg_len": i32(lens),
                   "last": i32(ends - 1), "M": m, "max_len": int(lens.max()),
+                  "k_off": i32(np.full(len(lens), pos0)) if pos0 else None, "max_klen": int(lens.max()) + pos0,
                   "kv_off": torch.from_numpy(np.asarray(slots, dtype=np.int64) * (cfg.num_key_value_heads * Lmax * cfg.head_dim)).to(dev)}
             if len(plans) > 64:
                 plans.clear()
             plans[key] = pl
         return pl
 
-    def _layers_prefill(self, h, cache: KVCache, seq_lens: Sequence[int], slots: Optional[Sequence[int]] = None, trace: Optional[list] = None):
-        """h bf16 [M][H] (packed rows of all sequences, positions start at 0) -> updated in place.
+    def _layers_prefill(self, h, cache: KVCache, seq_lens: Sequence[int], slots: Optional[Sequence[int]] = None, trace: Optional[list] = None,
+                        pos0: int = 0):
+        """h bf16 [M][H] (packed rows of all sequences, positions start at pos0: the cache already holds pos0 tokens of every
+        sequence) -> updated in place.
         `trace` (tests): a list that receives, per layer, a dict of clones of every intermediate the layer hands from one
         kernel to the next, so that each stage can be checked against the oracle from the inputs the GPU itself saw."""
         def keep(li, **kw):
@@ -281,9 +322,9 @@ class TextDecoder:
             slots = tuple(int(s) for s in slots)
             if len(slots) != len(seq_lens) or len(set(slots)) != len(slots) or min(slots) < 0 or max(slots) >= cache.batch:
                 raise ValueError(f"prefill: slots {slots} must be {len(seq_lens)} distinct rows of a cache of {cache.batch}")
-        if max(seq_lens) > cache.max_len:
-            raise ValueError(f"prefill: a sequence of {max(seq_lens)} tokens does not fit a cache of {cache.max_len}")
-        pl = self._prefill_plan(tuple(int(t) for t in seq_lens), cache.max_len, slots)
+        if pos0 < 0 or pos0 + max(seq_lens) > cache.max_len:
+            raise ValueError(f"prefill: {pos0} cached + {max(seq_lens)} new tokens do not fit a cache of {cache.max_len}")
+        pl = self._prefill_plan(tuple(int(t) for t in seq_lens), cache.max_len, slots, int(pos0))
         M, H, I = pl["M"], cfg.hidden_size, cfg.intermediate_size
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
@@ -311,7 +352,8 @@ class TextDecoder:
                          ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(q), ops.ptr(cache.k[li]),
                          ops.ptr(cache.v[li]), M, nh, nkv, hd, Lmax, ops.sp())
                 ops.attn_fwd(ops.ptr(q), qd, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), pl["kv_off"], Lmax * hd, hd, att, qd,
-                             pl["seg_start"], pl["seg_len"], len(seq_lens), pl["max_len"], nh, nkv, hd, True, scale)
+                             pl["seg_start"], pl["seg_len"], len(seq_lens), pl["max_len"], nh, nkv, hd, True, scale,
+                             seg_k_off=pl["k_off"], max_klen=pl["max_klen"])
                 ops.quantize_rows_fp8(att, a8, sa_, M, qd)
                 ops.gemm_fp8(a8, sa_, L["wo"], L["wo_s"], M, H, qd, h, res=h)
                 keep(li, q=q, att=att, a8=a8, sa=sa_, h_mid=h)
@@ -331,7 +373,8 @@ class TextDecoder:
                      ops.ptr(L["qn"]), ops.ptr(L["kn"]), ops.ptr(w["inv_freq"]), eps, ops.ptr(q), ops.ptr(cache.k[li]),
                      ops.ptr(cache.v[li]), M, nh, nkv, hd, Lmax, ops.sp())
             ops.attn_fwd(ops.ptr(q), qd, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), pl["kv_off"], Lmax * hd, hd, att, qd,
-                         pl["seg_start"], pl["seg_len"], len(seq_lens), pl["max_len"], nh, nkv, hd, True, scale)
+                         pl["seg_start"], pl["seg_len"], len(seq_lens), pl["max_len"], nh, nkv, hd, True, scale,
+                             seg_k_off=pl["k_off"], max_klen=pl["max_klen"])
             ops.gemm(att, L["wo"], M, H, qd, h, res=h, res_kind=2, ldres=H)
             keep(li, q=q, att=att, h_mid=h)
             ops.rmsnorm(h, L["ln2"], x, M, H, eps)
@@ -446,12 +489,23 @@ class TextDecoder:
                          slab=slab if epi == 0 else None, out=out, rt=rt, ksplit=ksplit, scale=holder[name + "_s"])
         return S
 
-    def _layers_decode(self, ws: DecodeWorkspace, cache: KVCache, pos) -> None:
+    def _layers_decode(self, ws: DecodeWorkspace, cache: KVCache, pos, trace: Optional[list] = None) -> None:
         """7 launches per layer, every GEMM operand in its streaming layout (W16 / X16):
         qkv GEMM (slabs) -> attention with fused QK-norm / RoPE / KV append -> o GEMM (slabs) ->
         residual + RMSNorm -> gate/up GEMM with SwiGLU epilogue -> down GEMM (slabs) -> residual + RMSNorm.
-        ws.x16 holds the normed input on entry and the final-norm output on exit."""
+        ws.x16 holds the normed input on entry and the final-norm output on exit.
+        `trace` (tests; the 7-launch form only): a list that receives, per layer, clones of what every launch handed to the
+        next -- operands back in row-major form, split-K slabs as written -- so that each stage can be checked against the
+        oracle from the inputs the GPU itself saw (tests/test_parity_gpu.py)."""
         cfg, w = self.config, self.w
+        if trace is not None and ws.fused_norm and self.fuse_norm:
+            raise ValueError("decode trace: the batch <= 2 form fuses the norms into the GEMMs; trace a batch of 3 or more")
+
+        def keep(li, **kw):
+            if trace is not None:
+                while len(trace) <= li:
+                    trace.append({})
+                trace[li].update({k: (v.clone() if hasattr(v, "clone") else v) for k, v in kw.items()})
         B, H, I = ws.B, cfg.hidden_size, cfg.intermediate_size
         nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         qd, qkvd = nh * hd, (nh + 2 * nkv) * hd
@@ -484,18 +538,34 @@ class TextDecoder:
                      ops.ptr(w["norm"]), ops.ptr(ws.x16), B, H, eps, ops.sp())
             return
         for li, L in enumerate(layers):
+            if trace is not None:
+                keep(li, x_in=ops.from_x16(ws.x16, B, ws.MT), h_in=ws.h)
             s_qkv = self._gemm3(ws, "qkv", ws.x16, L, "wqkv", qkvd, H, 0)
+            if trace is not None:
+                keep(li, qkv_slabs=ws.slab[: s_qkv * B * qkvd].view(s_qkv, B, qkvd))
             ops.call("q3asr_attn_decode_fused", ops.ptr(ws.slab), qkvd, s_qkv, B * qkvd, ops.ptr(L["qn"]), ops.ptr(L["kn"]),
                      ops.ptr(w["inv_freq"]), eps, ops.ptr(cache.k[li]), ops.ptr(cache.v[li]), ops.ptr(pos), ops.ptr(ws.att16),
                      B, nh, nkv, hd, Lmax, scale, ops.ptr(cache.attn_ws), ops.sp())
+            if trace is not None:
+                keep(li, att=ops.from_x16(ws.att16, B, ws.MT))
             s_o = self._gemm3(ws, "o", ws.att16, L, "wo", H, qd, 0)
+            if trace is not None:
+                keep(li, o_slabs=ws.slab[: s_o * B * H].view(s_o, B, H))
             ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_o, B * H, ops.ptr(ws.h), ops.ptr(ws.h),
                      ops.ptr(L["ln2"]), ops.ptr(ws.x16), B, H, eps, ops.sp())
+            if trace is not None:
+                keep(li, h_mid=ws.h, x_2=ops.from_x16(ws.x16, B, ws.MT))
             self._gemm3(ws, "gu", ws.x16, L, "wgu", 2 * I, H, 2, out=ws.act16)
+            if trace is not None:
+                keep(li, act=ops.from_x16(ws.act16, B, ws.MT))
             s_d = self._gemm3(ws, "down", ws.act16, L, "wdown", H, I, 0)
+            if trace is not None:
+                keep(li, down_slabs=ws.slab[: s_d * B * H].view(s_d, B, H))
             nxt = layers[li + 1]["ln1"] if li + 1 < len(layers) else w["norm"]
             ops.call("q3asr_slab_resnorm_x16", ops.ptr(ws.slab), s_d, B * H, ops.ptr(ws.h), ops.ptr(ws.h),
                      ops.ptr(nxt), ops.ptr(ws.x16), B, H, eps, ops.sp())
+            if trace is not None:
+                keep(li, h_out=ws.h, x_next=ops.from_x16(ws.x16, B, ws.MT))
 
     def gemm_only_step(self, ws: DecodeWorkspace) -> int:
         """bench.py roofline leg: exactly the weight-streaming GEMM launches of one decode step (4 per
@@ -571,53 +641,58 @@ class TextDecoder:
         _lib.call("q3asr_graph_launch", ws.graph_multi if use_multi else ws.graph, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         return self.MULTI_STEPS if use_multi else 1
 
-    # ------------------------------------------------------------------ reference-shaped call (batch 1)
+    # ------------------------------------------------------------------ reference-shaped call
     def __call__(self, inputs, cache: Optional[KVCache] = None, is_embeds: bool = False):
-        """Token ids (1,T) or embeddings (1,T,H) -> bf16 logits (1,T,V) for EVERY position, appending
-        to ``cache`` at ``cache.offset`` (reference decoder.py:219-253; the caller advances offset)."""
+        """Token ids (B,T) or embeddings (B,T,H) -> bf16 logits (B,T,V) for EVERY position, appending
+        to ``cache`` at ``cache.offset`` (reference decoder.py:219-253; the caller advances offset).  T > 1 on a non-empty
+        cache -- the case create_additive_causal_mask(N, offset) exists for -- runs the prefill kernels with every position
+        shifted by the offset; T == 1 on a non-empty cache runs the decode-step kernels."""
         import torch
         if self.w is None:
             raise TypeError("TextDecoder has no weights loaded")
         cfg, w, dev = self.config, self.w, self.device
         t = torch.as_tensor(inputs) if not isinstance(inputs, torch.Tensor) else inputs
         h = (t.to(dev, torch.bfloat16) if is_embeds else self.embed_tokens(t.to(dev)))
-        if h.ndim == 3:
-            if h.shape[0] != 1:
-                raise NotImplementedError("reference-shaped call is batch 1; use prefill()/generate_batch for batches")
-            h = h[0]
-        h = h.contiguous().clone()
-        T = h.shape[0]
+        if h.ndim == 2:
+            h = h[None]
+        B, T, H = h.shape
+        if T < 1 or B < 1:
+            raise ValueError(f"decoder call: empty input {tuple(h.shape)}")
+        if B > 64:
+            raise NotImplementedError("reference-shaped call: at most 64 sequences per call; use prefill()/generate_batch for larger batches")
+        hp = h.reshape(B * T, H).contiguous().clone()
         cache = cache if cache is not None else KVCache()
         off = cache.offset
-        if off + T > cache.max_len or cache.batch != 1:
-            cache.ensure(cfg, 1, max(off + T, 2 * cache.max_len, 64), dev)
-        if off == 0:
-            self._layers_prefill(h, cache, [T])
-            x = torch.empty_like(h)
-            ops.rmsnorm(h, w["norm"], x, T, cfg.hidden_size, cfg.rms_norm_eps)
-        elif T == 1:
-            x = self._single_step_hidden(h, cache, off)
+        if cache.batch != B and off > 0:
+            raise ValueError(f"decoder call: batch {B} on a cache holding {off} tokens of batch {cache.batch}")
+        if cache.k is None or off + T > cache.max_len or cache.batch != B or cache.k.shape[0] < cfg.num_hidden_layers:
+            cache.ensure(cfg, B, max(off + T, 2 * cache.max_len if cache.batch == B else 0, 64), dev)
+        if T == 1 and off > 0:
+            x = self._single_step_hidden(hp, cache, off)
         else:
-            raise NotImplementedError("multi-token call with a non-empty cache")
-        logits = torch.empty((T, cfg.vocab_size), dtype=torch.bfloat16, device=dev)
-        ops.gemm(x, w["embed"], T, cfg.vocab_size, cfg.hidden_size, logits)      # every position (decoder.py:252), bf16 rows of the tied embedding
-        return logits[None]
+            self._layers_prefill(hp, cache, [T] * B, pos0=off)
+            x = torch.empty_like(hp)
+            ops.rmsnorm(hp, w["norm"], x, B * T, H, cfg.rms_norm_eps)
+        logits = torch.empty((B * T, cfg.vocab_size), dtype=torch.bfloat16, device=dev)
+        ops.gemm(x, w["embed"], B * T, cfg.vocab_size, H, logits)      # every position (decoder.py:252), bf16 rows of the tied embedding
+        return logits.view(B, T, cfg.vocab_size)
 
     def _single_step_hidden(self, h, cache: KVCache, off: int):
-        """One token at position `off` through the decode kernels; returns the final-norm output."""
+        """One token per sequence (h bf16 [B][H]) at position `off` through the decode kernels; returns the final-norm output."""
         import torch
         cfg, w = self.config, self.w
+        B = h.shape[0]
         ws = self._api_ws
-        if ws is None:
-            ws = self._api_ws = DecodeWorkspace(cfg, 1, 1, self.device, fp8=getattr(self, "weight_dtype", "bf16") != "bf16",
+        if ws is None or ws.B != B:
+            ws = self._api_ws = DecodeWorkspace(cfg, B, 1, self.device, fp8=getattr(self, "weight_dtype", "bf16") != "bf16",
                                                 geo4_override=self.geo4_override)
         H, eps = cfg.hidden_size, cfg.rms_norm_eps
         ws.pos.fill_(off)
         layers = w["layers"]
-        ops.call("q3asr_embed_norm_x16", None, ops.ptr(h), 1, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]), ops.ptr(ws.x16), 1, H,
+        ops.call("q3asr_embed_norm_x16", None, ops.ptr(h), B, ops.ptr(ws.h), ops.ptr(layers[0]["ln1"]), ops.ptr(ws.x16), B, H,
                  eps, ops.sp())
         self._layers_decode(ws, cache, ws.pos)
-        return ops.from_x16(ws.x16, 1, ws.MT).contiguous()
+        return ops.from_x16(ws.x16, B, ws.MT).contiguous()
 
 
 def load_decoder_weights(decoder: TextDecoder, model_path: str | Path, device: Optional[str] = None,

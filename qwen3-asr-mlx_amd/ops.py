@@ -12,11 +12,38 @@ def off_ptr(t, elem_offset: int):
     return C.c_void_p(t.data_ptr() + elem_offset * t.element_size())
 
 
+# Chained stream-K workspaces of the 8-phase GEMM (include/q3asr.h, q3asr_gemm_bf16_ws): one zeroed block per (device, stream) --
+# launches on different streams may overlap and must not share accumulator slots.  64 MiB each; streams beyond the cap run the
+# whole-tile kernels (same bits).
+_gemm_ws: dict = {}
+_GEMM_WS_MAX = 12
+USE_GEMM_WORKSPACE = True
+
+
+def gemm_workspace(device):
+    if not USE_GEMM_WORKSPACE:
+        return None
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        if len(_gemm_ws) >= _GEMM_WS_MAX:
+            return None
+        nbytes = int(_lib.load().q3asr_gemm_workspace_bytes())
+        ws = _gemm_ws[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=device)
+    return ws
+
+
+def release_gemm_workspaces() -> None:
+    _gemm_ws.clear()
+
+
 def gemm(A, W, M, N, K, out, *, lda=None, ldw=None, bias=None, act=0, res=None, res_kind=0, ldres=0, res_mod=0,
          out_fp32=False, ldo=None, row_map=None):
-    call("q3asr_gemm_bf16", ptr(A), lda if lda is not None else K, ptr(W), ldw if ldw is not None else K, M, N, K,
+    ws = gemm_workspace(out.device) if ((M + 255) // 256) * ((N + 255) // 256) > 256 else None      # only launches of more than 256 tiles use it
+    call("q3asr_gemm_bf16_ws", ptr(A), lda if lda is not None else K, ptr(W), ldw if ldw is not None else K, M, N, K,
          ptr(bias), act, ptr(res), res_kind, ldres, res_mod, ptr(out), 1 if out_fp32 else 0,
-         ldo if ldo is not None else (N // 2 if act == 2 else N), ptr(row_map), sp())
+         ldo if ldo is not None else (N // 2 if act == 2 else N), ptr(row_map), ptr(ws), 0 if ws is None else ws.numel(), sp())
 
 
 def conv_weight_chunked(w):
@@ -37,8 +64,10 @@ def conv3x3s2(x, imgs, Hin, Win, Cin, w, Cout, bias, act, out, out_fp32=False):
 
 def gemm_fp8(A8, a_scale, W8, w_scale, M, N, K, out, act=0, res=None, ldo=None):
     """fp8 x fp8 GEMM (csrc/gemm.hip, q3asr_gemm_fp8): bytes [M][K] x bytes [N][K] -> bf16; res: bf16 residual (MLX add)."""
-    call("q3asr_gemm_fp8", ptr(A8), K, ptr(a_scale), ptr(W8), K, ptr(w_scale), M, N, K, act, ptr(res), 2 if res is not None else 0,
-         N if res is not None else 0, ptr(out), ldo if ldo is not None else (N // 2 if act == 2 else N), sp())
+    ws = gemm_workspace(out.device) if ((M + 255) // 256) * ((N + 255) // 256) > 256 else None
+    call("q3asr_gemm_fp8_ws", ptr(A8), K, ptr(a_scale), ptr(W8), K, ptr(w_scale), M, N, K, act, ptr(res), 2 if res is not None else 0,
+         N if res is not None else 0, ptr(out), ldo if ldo is not None else (N // 2 if act == 2 else N), ptr(ws),
+         0 if ws is None else ws.numel(), sp())
 
 
 def rmsnorm_fp8(x, w, y8, scale, M, D, eps):
@@ -63,9 +92,11 @@ def rmsnorm(x, w, y, M, D, eps, ldx=None, ldy=None, row_idx=None):
 
 
 def attn_fwd(Q, q_stride, K, V, kv_seg_off, kv_head_stride, kv_row_stride, O, o_stride, seg_q_start, seg_len, n_segs,
-             max_len, n_heads, n_kv_heads, head_dim, causal, scale):
+             max_len, n_heads, n_kv_heads, head_dim, causal, scale, seg_k_off=None, max_klen=None):
+    """seg_k_off / max_klen: keys already cached in front of each segment's first query row (include/q3asr.h)."""
     call("q3asr_attn_fwd", Q, q_stride, K, V, ptr(kv_seg_off), kv_head_stride, kv_row_stride, ptr(O), o_stride,
-         ptr(seg_q_start), ptr(seg_len), n_segs, max_len, n_heads, n_kv_heads, head_dim, 1 if causal else 0, scale, sp())
+         ptr(seg_q_start), ptr(seg_len), ptr(seg_k_off), n_segs, max_len, max_len if max_klen is None else max_klen,
+         n_heads, n_kv_heads, head_dim, 1 if causal else 0, scale, sp())
 
 
 # ---------------------------------------------------------------- decode-step streaming layouts

@@ -621,6 +621,92 @@ def test_kv_cache_and_mask_api(dev, small):
     assert model._decoder.embed_tokens.weight.shape == (t.vocab_size, t.hidden_size)
 
 
+def test_kv_cache_update_method(dev):
+    """KVCache.update(layer_idx, key, value) as in reference decoder.py:32-64 / tests/test_decoder.py:254-283: the first call
+    of a layer stores, later calls concatenate on axis 2, the full accumulated (key, value) comes back, `offset` is the
+    caller's; layers may arrive in order from an empty cache."""
+    import qwen3_asr_mlx_amd as q
+    g = torch.Generator().manual_seed(3)
+    cache = q.KVCache()
+    B, nkv, hd = 1, 8, 128
+    k1, v1 = torch.randn(B, nkv, 5, hd, generator=g).to(torch.bfloat16), torch.randn(B, nkv, 5, hd, generator=g).to(torch.bfloat16)
+    for layer in range(3):
+        fk, fv = cache.update(layer, k1.to(dev), v1.to(dev))
+        assert fk.shape == (B, nkv, 5, hd) and fv.shape == (B, nkv, 5, hd)
+        assert torch.equal(fk.cpu(), k1) and torch.equal(fv.cpu(), v1)
+    assert cache.offset == 0 and len(cache.keys) == 3 and cache.keys[1].shape == (B, nkv, 5, hd)
+    cache.offset = 5                                                       # generate.py:275
+    k2, v2 = torch.randn(B, nkv, 1, hd, generator=g).to(torch.bfloat16), torch.randn(B, nkv, 1, hd, generator=g).to(torch.bfloat16)
+    for layer in range(3):
+        fk, fv = cache.update(layer, k2.to(dev), v2.to(dev))
+        assert fk.shape == (B, nkv, 6, hd)
+        assert torch.equal(fk.cpu(), torch.cat([k1, k2], dim=2)) and torch.equal(fv.cpu(), torch.cat([v1, v2], dim=2))
+    cache.offset += 1
+    big = torch.randn(B, nkv, 100, hd, generator=g).to(torch.bfloat16)       # past the first allocation: contents survive the growth
+    fk, _ = cache.update(0, big.to(dev), big.to(dev))
+    assert fk.shape == (B, nkv, 106, hd) and torch.equal(fk[:, :, :6].cpu(), torch.cat([k1, k2], dim=2)) and torch.equal(fk[:, :, 6:].cpu(), big)
+    assert cache.values[1].shape == (B, nkv, 6, hd)                         # the other layers are where they were
+    with pytest.raises(ValueError):
+        cache.update(0, big[:, :4].to(dev), big[:, :4].to(dev))           # 4 kv heads on an 8-head cache
+    with pytest.raises(ValueError):
+        cache.update(0, big.to(dev), big[:, :, :3].to(dev))               # key / value shapes differ
+
+
+def test_decoder_call_appends_several_tokens_to_a_filled_cache(dev, small):
+    """TextDecoder.__call__ with T > 1 on a non-empty cache (reference decoder.py:151-158: RoPE offset = cache.offset, mask
+    = create_additive_causal_mask(T, offset)): prefill 300 tokens, append 108, against ONE 408-token call -- the appended
+    rows' logits must be the same bits (every kernel on the path is row-independent; a query row's extra, wholly masked key
+    tile adds exact zeros) -- and against the oracle, which supports the same call (oracle/decoder.py forward at offset > 0).
+    Also a batch of 2 in one call against two single calls, and a one-token call after the append."""
+    import oracle
+    import qwen3_asr_mlx_amd as q
+    cfg, state, model = small
+    t = cfg.text_decoder
+    dec = model._decoder
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, t.vocab_size, (1, 409), generator=g)
+    one = q.KVCache()
+    full = dec(ids[:, :408], cache=one)                                    # (1, 408, V)
+    two = q.KVCache()
+    a = dec(ids[:, :300], cache=two)
+    two.offset = 300
+    b = dec(ids[:, 300:408], cache=two)
+    two.offset = 408
+    assert a.shape == (1, 300, t.vocab_size) and b.shape == (1, 108, t.vocab_size)
+    assert torch.equal(a, full[:, :300]) and torch.equal(b, full[:, 300:])
+    assert torch.equal(two.keys[-1], one.k[-1][:, :, :408]) and torch.equal(two.values[0], one.v[0][:, :, :408])
+    # an offset that is not a multiple of the key tile and an append that crosses tile boundaries: 37 + 200
+    three = q.KVCache()
+    dec(ids[:, :37], cache=three)
+    three.offset = 37
+    c = dec(ids[:, 37:237], cache=three)
+    assert torch.equal(c, full[:, 37:237])
+    # the oracle on the same split (bf16 logits: 2 ulps of the top logit, the small-config bar of test_parity_gpu)
+    _, odec = _oracle_parts(cfg, state)
+    odec.reset()
+    odec.forward(odec.embed(ids[0, :300].tolist()))
+    ref = odec.forward(odec.embed(ids[0, 300:408].tolist()), last_only=False)
+    assert float((b[0].float().cpu() - ref).abs().max()) <= LOGIT_ATOL             # the bar of this file's other logit checks
+    # one more token through the decode-step kernels at offset 408, against the oracle's next row
+    nxt = dec(ids[:, 408:409], cache=two)
+    ref1 = odec.forward(odec.embed(ids[0, 408:409].tolist()))[0]
+    assert float((nxt[0, 0].float().cpu() - ref1).abs().max()) <= LOGIT_ATOL
+    # a batch of two sequences in one call == the two single calls (rows never see their batch mates)
+    ids2 = torch.randint(0, t.vocab_size, (2, 70), generator=g)
+    cb = q.KVCache()
+    both = dec(ids2[:, :50], cache=cb)
+    cb.offset = 50
+    both2 = dec(ids2[:, 50:], cache=cb)
+    for r in range(2):
+        cs = q.KVCache()
+        s1 = dec(ids2[r: r + 1, :50], cache=cs)
+        cs.offset = 50
+        s2 = dec(ids2[r: r + 1, 50:], cache=cs)
+        assert torch.equal(both[r], s1[0]) and torch.equal(both2[r], s2[0])
+    with pytest.raises(ValueError):
+        dec(ids2[:1, :5], cache=cb)                                        # batch 1 on a cache holding batch 2
+
+
 def test_log_mel_public_function(dev):
     """reference tests/test_audio.py:41-95 against the HIP frontend."""
     import qwen3_asr_mlx_amd as q
@@ -631,8 +717,8 @@ def test_log_mel_public_function(dev):
     sil = q.log_mel_spectrogram(np.zeros(16000, dtype=np.float32))
     assert torch.allclose(sil, torch.full_like(sil, -1.5), atol=1e-6)
     assert float(one_s.max() - one_s.min()) <= 2.0 + 1e-6
-    with pytest.raises(NotImplementedError):
-        q.log_mel_spectrogram(signal("noise", 16000), n_fft=512)
+    other = q.log_mel_spectrogram(signal("noise", 16000), n_fft=512, hop_length=128, n_mels=80)      # audio.py:238-246 accepts any triple
+    assert other.shape == (80, 125) and other.dtype == torch.float32
 
 
 def test_pack_audio_reuses_its_pinned_buffer_only_after_the_copy(dev):

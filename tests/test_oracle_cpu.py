@@ -46,6 +46,32 @@ def test_mel_bit_exact_against_reference_fixtures():
     assert np.array_equal(oracle.stft_power(signal("noise", 8000)), np.load(GOLD / "stft_power_noise_0.5s.npy"))
 
 
+MEL_PARAM_SIGNALS = {"fft512_hop128_mels80": ("noise", 16000), "fft256_hop100_mels40_sr8k": ("speechlike", 8000),
+                     "fft400_hop200": ("noise", 1234), "fft1024_hop256_mels64": ("tone", 16000),
+                     "fft201_hop67_mels20_odd": ("noise", 5000), "fft400_hop160_mels128_fmax4k": ("speechlike", 16000),
+                     "fft64_hop16_mels8_short": ("noise", 40)}          # the inputs tools/gen_golden_mel_params.py used
+
+
+def mel_param_cases():
+    meta = json.loads((GOLD / "mel_params.json").read_text())
+    arrs = np.load(GOLD / "mel_params.npz")
+    for name, m in meta.items():
+        kind, n = MEL_PARAM_SIGNALS[name]
+        yield name, signal(kind, n), m["params"], arrs[name]
+
+
+def test_mel_non_default_parameters_bit_exact_against_reference_fixtures():
+    """audio.py:238-246 accepts any n_fft / hop_length / n_mels / sample_rate / f_min / f_max; fixtures from the live reference
+    (tools/gen_golden_mel_params.py), odd n_fft and a 2-frame signal included."""
+    n = 0
+    for name, x, params, want in mel_param_cases():
+        p = dict(params)
+        got = oracle.log_mel_spectrogram(x, p.pop("n_fft"), p.pop("hop_length"), p.pop("n_mels"), **p)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        n += 1
+    assert n == 7
+
+
 def test_mel_reference_test_properties():
     """reference tests/test_audio.py:49-89."""
     assert oracle.log_mel_spectrogram(signal("noise", 16000)).shape == (128, 100)

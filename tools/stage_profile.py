@@ -36,7 +36,7 @@ def shape_of(name, a):
     if name == "q3asr_conv3x3s2_bf16":
         return f"imgs={v(a[1])} {v(a[2])}x{v(a[3])}x{v(a[4])} -> Cout={v(a[6])}"
     if name == "q3asr_attn_fwd":
-        return f"segs={v(a[11])} max={v(a[12])} hd={v(a[15])} causal={v(a[16])}"
+        return f"segs={v(a[12])} max={v(a[13])} hd={v(a[17])} causal={v(a[18])}"
     if name in ("q3asr_layernorm_f32_bf16",):
         return f"M={v(a[4])} D={v(a[5])}"
     if name == "q3asr_rmsnorm_bf16":
