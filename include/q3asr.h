@@ -71,27 +71,16 @@ int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, int Cin, con
 int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
                     const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
                     void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream);
-/* The same two GEMMs with a workspace for the 8-phase kernel's chained stream-K form (csrc/gemm.hip): launches whose 256 x 256
- * tiles do not fill whole rounds of the 256 CUs give every workgroup the same number of K iterations instead, a tile that two
- * workgroups share has its MFMA chains CONTINUED from published accumulators (never summed from partials), so results are
- * bit-identical to the calls above.  workspace: q3asr_gemm_workspace_bytes() bytes of device memory, 128-byte aligned, ZEROED
- * ONCE by the caller and then handed to every call on ONE stream (concurrent streams need a block each); NULL = the calls above. */
-int64_t q3asr_gemm_workspace_bytes(void);
-int q3asr_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
-                       const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
-                       void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* workspace, int64_t workspace_bytes, void* stream);
 /* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 64 = 64x64 tile, 128 = 128x128 tile, 8 = 256x256 8-phase LDS-DMA
  * pipeline where its preconditions hold, 224 = the same pipeline on 224x256 tiles).  All kernels give bit-identical results. */
 int q3asr_gemm_force_kernel(int mode);
 /* Diagnostic: 0 = every sub-tile of the 8-phase kernels takes the general (bounds-tested) epilogue, 1 = interior sub-tiles take the short one (default). Same bits either way; returns the previous setting. Used by tools/ab_gemm_epilogue.py */
 int q3asr_gemm_set_interior(int on);
 /* Diagnostic: switches between two launch forms with identical results, for A/B measurements in one process (tools/ab_step.py,
- * tools/bench_head.py).  Every option defaults to 1 (the test hook 4 to 0); returns the previous value, or -1 for an unknown option.  A captured
+ * tools/bench_head.py).  Every option defaults to 1; returns the previous value, or -1 for an unknown option.  A captured
  * graph keeps the form it was captured with. */
 #define Q3ASR_OPT_HEAD_XCD_MAP 1    /* tied head: workgroups that share a 128-byte logits line run on one XCD */
 #define Q3ASR_OPT_HEAD_STREAM 2     /* tied head (bf16, K = 2048, geometry 2/8/8, <= 32 rows): one workgroup per CU walking its tile groups */
-#define Q3ASR_OPT_GEMM_STREAMK 3    /* 8-phase GEMM: chained stream-K where a workspace came with the call (0: whole tiles per workgroup) */
-#define Q3ASR_OPT_GEMM_SK_RECOMPUTE 4 /* test hook, default 0: every tail piece of a chained stream-K launch gives up on its hand-off and recomputes (same bits) */
 int q3asr_set_option(int option, int value);
 /* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
 int q3asr_gemm_set_stamp(void* buf);
@@ -119,8 +108,7 @@ int q3asr_attn_fwd_f32(const float* qkv, int64_t ld, int d_model, const int32_t*
  * act: 0 none, 2 SwiGLU (weights interleaved as for q3asr_gemm_bf16); res_kind: 0 none, 2 bf16 residual. */
 int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
                    int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo, void* stream);
-int q3asr_gemm_fp8_ws(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
-                   int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* RMSNorm (decoder.py:189,194) with the bf16 result quantised per row: y8 = e4m3(y / scale[m]), scale = max|y| / 448 */
 int q3asr_rmsnorm_bf16_fp8(const void* x, int64_t ldx, const void* w, void* y8, int64_t ldy, float* scale, int M, int D, float eps,
                            void* stream);

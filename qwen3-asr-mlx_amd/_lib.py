@@ -28,9 +28,6 @@ _SIGS = {
     "q3asr_conv3x3s2_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _vp, _vp],
     "q3asr_gemm_bf16": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _i, _i64, _vp, _vp],
     "q3asr_gemm_fp8": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _i64, _vp, _i64, _vp],
-    "q3asr_gemm_workspace_bytes": [],
-    "q3asr_gemm_bf16_ws": [_vp, _i64, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _i, _i64, _vp, _vp, _i64, _vp],
-    "q3asr_gemm_fp8_ws": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _i64, _vp, _i64, _vp, _i64, _vp],
     "q3asr_rmsnorm_bf16_fp8": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _f, _vp],
     "q3asr_quantize_rows_fp8": [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp],
     "q3asr_layernorm_f32_bf16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
@@ -62,8 +59,7 @@ _SIGS = {
     "q3asr_event_elapsed_ms": [_vp, _vp, C.POINTER(_f)],
     "q3asr_event_destroy": [_vp],
 }
-_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p, "q3asr_attn_decode_fused_workspace": C.c_int64,
-             "q3asr_gemm_workspace_bytes": C.c_int64}
+_RESTYPES = {"q3asr_arch": C.c_char_p, "q3asr_last_error": C.c_char_p, "q3asr_attn_decode_fused_workspace": C.c_int64}
 EXPORTS = tuple(_SIGS)
 
 

@@ -23,8 +23,6 @@ extern "C" void q3asr_set_error(const char* fmt, ...);
 extern int g_q3_option[8];
 #define Q3ASR_OPT_HEAD_XCD_MAP 1      // the ids of include/q3asr.h
 #define Q3ASR_OPT_HEAD_STREAM 2
-#define Q3ASR_OPT_GEMM_STREAMK 3
-#define Q3ASR_OPT_GEMM_SK_RECOMPUTE 4
 int q3_check_launch(const char* what);
 
 #define Q3_REQUIRE(cond, ...)                 \

@@ -39,9 +39,6 @@ struct GemmParams {
     const float* a_scale; const float* w_scale;
     unsigned long long* stamp;   // diagnostic (q3asr_gemm_set_stamp): workgroup stamp_wg records wall_clock64() at its phase boundaries
     int stamp_wg;
-    // chained stream-K (8-phase kernel, plain GEMMs): accumulator slots [grid][32 f32x4][512 threads] + one flag line per slot
-    float* sk_ws; unsigned* sk_flags;
-    int sk_spins;            // polls before a tail piece gives up and recomputes its tile's head; < 0 (test hook): give up without looking
 };
 
 // 128-byte rows: two rows make one 256-byte bank row, so the XOR uses row >> 1 and the row parity supplies the 4th bit:
@@ -785,29 +782,6 @@ __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0
 // of its four MFMA tiles; the half-tile images keep their 128-row slots, the unused 16 rows per wave row are staged and ignored).
 // Round 3: M = 12,480 / 13,056 rows make 196 / 408 / 784 / 816 tiles of 256 rows on 256 CUs -- rounds that are 77-80 % full --
 // and 224 / 472 / 896 / 944 tiles of 224: the same number of rounds, each 0.875 of the work (gemm_launch picks per shape).
-//
-// Round 5: CHAINED STREAM-K (p.sk_ws != nullptr; plain GEMMs with more tiles than workgroups).  The launch's work is the
-// list of (tile, K iteration) pairs in tile order, an iteration = two K tiles = one trip of the 8-phase loop; workgroup w of
-// G takes the contiguous range [w U / G, (w + 1) U / G) of the U = tiles x iterations pairs, so every workgroup computes the
-// same amount (to one iteration) whatever tiles mod G is -- 784 tiles are 3.06 rounds of work, not 4 -- and the workgroups
-// reach their epilogues at different times instead of storing a round's 32 MB as one burst.  A range starts and ends inside a
-// tile.  What keeps the results BIT-IDENTICAL to the one-workgroup-per-tile kernels is that a split tile is never summed from
-// partial products: its MFMA chains are CONTINUED.  The workgroup whose range ends inside tile b runs that piece -- K
-// iterations 0 .. kb-1, from zero accumulators -- FIRST and publishes its 128 accumulator registers per lane (256 KiB of fp32,
-// write-through stores, one flag); the workgroup whose range starts inside tile b runs its piece LAST: it loads those
-// accumulators and carries the same k-ascending chains on from iteration kb, then runs the tile's epilogue.  Every output
-// element sees the MFMAs of its chain in the same order with the same operands as in a whole-tile pass, and fp32 registers
-// survive the trip through memory exactly.  Dependencies point from a piece that ran at the very start of a launch to one
-// that runs at its very end, in ANOTHER workgroup, so nobody waits in practice; the wait is bounded all the same (a consumer
-// that gives up marks the flag and computes the tile's first iterations itself -- same chains, same bits -- so no dispatch
-// order, residency or concurrency assumption is needed for completion: with two such launches on different streams the
-// hardware may leave workgroups of either undispatched while residents spin).  Hand-off protocol: MI355X guide, Guideline 16
-// R1 (payload sc1 + every storing wave's vmcnt(0) + barrier + one agent-scope atomic; consumer: one lane polls relaxed, ONE
-// agent acquire, vmcnt(0), barrier, plain loads).  Flags return to 0 inside the launch (consumer after its loads; producer
-// when it finds the cancel mark), so a zero-initialised workspace serves every later launch on its stream without a memset.
-struct G8Seg { int m0, n0, ib, ie, kind; };                                // kind 0: whole tile (or its recomputation), 1: head piece (publish), 2: tail piece (continue)
-#define G8_SK_SPINS 4096                                                   // default p.sk_spins; x s_sleep(32) ~ 2,048 cycles: ~4 ms before a consumer gives up
-
 template <int CONV, int MI1 = 4>      // CONV 0: plain bf16, 1: implicit-GEMM conv (bf16), 2: plain fp8 (e4m3 x e4m3, scales in the epilogue)
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int total_tiles) {
     constexpr int MI = 4 + MI1, WR = 16 * MI, TM = 2 * WR;                 // MFMA row tiles per wave, rows per wave row, rows per tile
@@ -817,12 +791,17 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = (p.N + G2_T - 1) / G2_T, tiles_m = (p.M + TM - 1) / TM;
     const int group = GROUP_M * tiles_n;
-    auto tile_origin = [&](unsigned t, int& m0, int& n0) {                  // grouped order: GROUP_M row tiles x all column tiles, rows fastest
+    auto tile_origin = [&](int v, int& m0, int& n0) {                       // same grouped, XCD-aware order as the other kernels
+        const unsigned t = xcd_remap((unsigned)v, (unsigned)total_tiles);
         const int first_m = (t / group) * GROUP_M;
         const int gm = min(tiles_m - first_m, GROUP_M);
         m0 = (first_m + (int)(t % group) % gm) * TM;
         n0 = ((int)(t % group) / gm) * G2_T;
     };
+    int v = blockIdx.x, m0, n0, m0n, n0n;
+    tile_origin(v, m0, n0);
+    m0n = m0; n0n = n0;
+    if (v + (int)gridDim.x < total_tiles) tile_origin(v + gridDim.x, m0n, n0n);
     const int wr = wave >> 2, wc = wave & 3, g = lane >> 4, li = lane & 15;
 
     G8Ctx c;
@@ -841,59 +820,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
         const int slot = (lane & 7) ^ ((rr >> 1) & 7);                      // k slot whose bytes belong at that position (same for q = 0, 1)
         c.kslot[0] = c.kslot[1] = 8 * slot;
     }
-
-    // ---- this workgroup's segments
-    const int I = c.nk >> 1;                                                // K iterations (two K tiles, 8 phases) per tile
-    // compiled for the bf16 kernel only: in the fp8 instantiation the extra accumulator definitions (loaded / zeroed) cost the
-    // register allocator ~90 spilled accumulator registers around the epilogue (ISA, round 5); its launches keep whole tiles
-    constexpr bool SKC = CONV == 0;
-    const bool sk = SKC && p.sk_ws != nullptr;                              // uniform
-    int nseg, has_head = 0, has_tail = 0, s_first = 0, s_last = 0, ka = 0, kb = I, my = (int)blockIdx.x, sk_n = 0;
-    if (sk) {
-        my = (int)xcd_remap(blockIdx.x, gridDim.x);                         // the workgroups of one XCD hold neighbouring ranges (speed only)
-        const long U = (long)total_tiles * I;
-        const long u0 = (long)my * U / (long)gridDim.x, u1 = (long)(my + 1) * U / (long)gridDim.x;
-        const int s_tail = (int)(u0 / I);                                   // slot my range starts in
-        s_last = (int)((u1 - 1) / I);                                       // slot it ends in
-        ka = (int)(u0 - (long)s_tail * I); kb = (int)(u1 - (long)s_last * I);
-        has_tail = ka > 0; has_head = kb < I;                               // host: total_tiles >= gridDim.x, so a range never lies inside one slot
-        s_first = s_tail + has_tail;                                        // first slot that STARTS in my range
-        nseg = s_last - s_first + 1 + has_tail;
-        sk_n = total_tiles / (int)gridDim.x;
-    } else {
-        nseg = CONV == 1 ? 1 : (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    }
-    // Slot -> tile.  A range is contiguous in SLOTS; which tile a slot holds is free as long as both workgroups that share a slot
-    // agree, so the k-th slot that starts in workgroup w's range holds tile k G + w of the grouped order (the slots of the last,
-    // partial round: n G + their rank among the workgroups that own one).  At any moment the 32 workgroups of an XCD -- consecutive
-    // w -- are then on 32 CONSECUTIVE tiles of the grouped order, 8 row tiles x 4 column tiles that share their operand panels
-    // in the XCD's L2, exactly as the whole-tile persistent loop has them.  (Slots in plain tile order put those 32 workgroups on
-    // every W-th tile of a window of 32 W: with W = 9.6 on 32 different weight panels at once, and the prefill's gate/up GEMM ran
-    // 41 % slower than with whole tiles; first measurement of round 5, profiles/r05_streamk.txt.)
-    auto slot_tile = [&](int slot, int w) {                                 // w = the workgroup in whose range the slot starts
-        const long U = (long)total_tiles * I;
-        const int first = (int)(((long)w * U / (long)gridDim.x + I - 1) / I);
-        const int k = slot - first;
-        return k < sk_n ? k * (int)gridDim.x + w : sk_n * (int)gridDim.x + (first - sk_n * w);
-    };
-    auto seg_at = [&](int j, G8Seg& sg) {
-        sg.ib = 0; sg.ie = I; sg.kind = 0;
-        if (!sk) {                                                          // tile blockIdx + j grid of the XCD-aware order
-            tile_origin(xcd_remap((unsigned)((int)blockIdx.x + j * (int)gridDim.x), (unsigned)total_tiles), sg.m0, sg.n0);
-            return;
-        }
-        // order of execution: the head piece (my last slot, if I own only part of it) FIRST, my whole slots, the tail piece LAST
-        int slot, w = my;
-        if (has_head && j == 0) { slot = s_last; sg.ie = kb; sg.kind = 1; }
-        else if (has_tail && j == nseg - 1) { slot = s_first - 1; w = my - 1; sg.ib = ka; sg.kind = 2; }
-        else slot = s_first + j - has_head;
-        tile_origin((unsigned)slot_tile(slot, w), sg.m0, sg.n0);
-    };
-    G8Seg cur, nxt;
-    seg_at(0, cur);
-    seg_at(min(1, nseg - 1), nxt);
-    const int m0 = cur.m0, n0 = cur.n0;                                      // the conv variant's only tile
-
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -928,83 +854,29 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
 #define G8_STAMP() do { if (p.stamp && (int)blockIdx.x == p.stamp_wg && tid == 0 && n_stamp < 16) p.stamp[n_stamp++] = wall_clock64(); } while (0)
     G8_STAMP();                                                             // 0: entry (after the address setup)
 
-    // ---- fill the ring for segment sg: S[0..6] in flight from its first K tile, S[0] (B0) and S[1] landed before the first reads.
-    // Also the restart of a tail piece whose head never arrived (every DMA drained and every wave past a barrier by then).
-    auto prime = [&](const G8Seg& sg) {
-        const int k0 = 2 * sg.ib;
-        g8_issue<0, 0, CONV, WR>(c, k0, sg.m0, sg.n0); g8_issue<1, 1, CONV, WR>(c, k0, sg.m0, sg.n0); g8_issue<2, 2, CONV, WR>(c, k0, sg.m0, sg.n0);
-        g8_issue<3, 3, CONV, WR>(c, k0, sg.m0, sg.n0); g8_issue<0, 4, CONV, WR>(c, k0 + 1, sg.m0, sg.n0); g8_issue<1, 5, CONV, WR>(c, k0 + 1, sg.m0, sg.n0);
-        g8_issue<2, 6, CONV, WR>(c, k0 + 1, sg.m0, sg.n0);
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        G8_BAR();
-        g8_read_b<0>(c, b0e);
-    };
-    prime(cur);
+    // ---- prologue: S[0..6] in flight, S[0] (B0 of tile 0) and S[1] landed before the first reads
+    g8_issue<0, 0, CONV, WR>(c, 0, m0, n0); g8_issue<1, 1, CONV, WR>(c, 0, m0, n0); g8_issue<2, 2, CONV, WR>(c, 0, m0, n0);
+    g8_issue<3, 3, CONV, WR>(c, 0, m0, n0); g8_issue<0, 4, CONV, WR>(c, 1, m0, n0); g8_issue<1, 5, CONV, WR>(c, 1, m0, n0);
+    g8_issue<2, 6, CONV, WR>(c, 1, m0, n0);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    G8_BAR();
+    g8_read_b<0>(c, b0e);
     G8_STAMP();                                                             // 1: pipeline filled
 
-    constexpr long SK_SLOT_F4 = 512L * 4 * MI;                              // f32x4 per accumulator slot: [4 MI registers][512 threads]
-    int j = 0;
+    const int iters = c.nk >> 1;                                            // two K tiles (8 phases) per trip
+    const int last_it = iters - 1;                                          // the DMA runs 7 half-tiles ahead: the last trip feeds the next tile
     while (true) {
-        bool zero = true;
-        if constexpr (SKC) {
-            if (cur.kind == 2) {                                            // tail piece: continue the chains workgroup my - 1 started
-                unsigned* flag = p.sk_flags + 32 * (my - 1);
-                volatile int* word = reinterpret_cast<volatile int*>(smem8 + 8 * G8_SLOT);   // wave 0's epilogue staging: idle between tiles
-                if (tid == 0) {
-                    int ok = 0;
-                    for (int spin = 0; spin < p.sk_spins; ++spin) {
-                        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) { ok = 1; break; }
-                        __builtin_amdgcn_s_sleep(32);
-                    }
-                    if (!ok) {                                              // give up: mark the flag (a publish that slipped in counts) ...
-                        ok = __hip_atomic_exchange(flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
-                        if (ok && p.sk_spins < 0) {                         // ... except under the test hook, which recomputes regardless
-                            __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = 0;
-                        }
-                    }
-                    if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    *word = ok;
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the acquire's invalidate has completed (wave 0); every wave's ring DMAs have landed
-                G8_BAR();
-                const int ok = *word;                                       // uniform
-                if (ok) {
-                    // one lane offset (from an opaque copy of the thread id: hoisted out of the tile loop, 32 address pairs were
-                    // spilled around the K loop) + a scalar offset per register
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        reinterpret_cast<f32x4*>(p.sk_ws) + (long)(my - 1) * SK_SLOT_F4, 0, (int)(SK_SLOT_F4 * 16), 0x00020000);
-                    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                    int tid2 = tid;
-                    asm volatile("" : "+v"(tid2));
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int i = 0; i < MI; ++i)
-                            acc[jj][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tid2 * 16, (jj * MI + i) * 8192, 0));
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    G8_BAR();                                               // every wave holds its accumulators: the slot may be handed back
-                    if (tid == 0) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    zero = false;
-                } else {                                                    // the tile from its first iteration, on a ring primed again
-                    cur.ib = 0; cur.kind = 0;
-                    prime(cur);
-                }
-            }
-        }
-        if (zero) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[jj][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (wr == 1) G8_BAR();                                             // the second wave row runs one barrier behind
-        for (int it = cur.ib; it < cur.ie; ++it) {
+        for (int it = 0; it < iters; ++it) {
             const int t2 = 2 * it;
-            const bool seam = CONV != 1 && it == cur.ie - 1;               // uniform: issues beyond this segment's K range belong to the next one
-            const int im0 = seam ? nxt.m0 : cur.m0, in0 = seam ? nxt.n0 : cur.n0;
-            const int wrap = seam ? 2 * (cur.ie - nxt.ib) : 0;
-            g8_phase<0, CONV, MI1>(c, t2 + 1, cur.m0, cur.n0, acc, af, b1, b0e, b0o);    // S[8it+7]  = A1 of tile 2it+1
+            const bool seam = CONV != 1 && it == last_it;                  // uniform: issues beyond this tile's K belong to the next tile
+            const int im0 = seam ? m0n : m0, in0 = seam ? n0n : n0;
+            const int wrap = seam ? c.nk : 0;
+            g8_phase<0, CONV, MI1>(c, t2 + 1, m0, n0, acc, af, b1, b0e, b0o);            // S[8it+7]  = A1 of tile 2it+1
             g8_phase<1, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // S[8it+8]  = B0 of tile 2it+2
             g8_phase<2, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);
             g8_phase<3, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // reads B0 of tile 2it+1 into b0o
@@ -1014,52 +886,29 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
             g8_phase<7, CONV, MI1>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
         }
         if (wr == 0) G8_BAR();                                             // re-align the wave rows
-        G8_STAMP();                                                         // 2 + 2t: K loop of segment t done
-        bool publish = false;
-        if constexpr (SKC) publish = cur.kind == 1;
-        if (publish) {                                                      // head piece: the accumulators travel, the tile's epilogue is the consumer's
-            if constexpr (SKC) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    reinterpret_cast<f32x4*>(p.sk_ws) + (long)my * SK_SLOT_F4, 0, (int)(SK_SLOT_F4 * 16), 0x00020000);
-                typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-                int tid2 = tid;
-                asm volatile("" : "+v"(tid2));                             // keep the offsets out of the K loop's live ranges
+        G8_STAMP();                                                         // 2 + 2t: K loop of tile t done
+        if constexpr (CONV == 2) {                                          // fp8: per-token and per-weight-row scales (fp32)
+            int lane2 = lane;
+            asm volatile("" : "+v"(lane2));                                // keep these addresses out of the K loop's live ranges
+            const int g2 = lane2 >> 4, li2 = lane2 & 15;
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
+            for (int j = 0; j < 4; ++j) {
+                const int nb = min(n0 + wc * 64 + j * 16 + 4 * g2, p.N - 4);
+                const f32x4 sw = *reinterpret_cast<const f32x4*>(p.w_scale + nb);
 #pragma unroll
-                    for (int i = 0; i < MI; ++i)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, acc[jj][i]), rs, tid2 * 16, (jj * MI + i) * 8192, 16);   // aux 16 = sc1: write-through
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // EVERY storing wave drains before the flag
-                G8_BAR();
-                if (tid == 0) {
-                    unsigned* flag = p.sk_flags + 32 * my;
-                    if (__hip_atomic_exchange(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u)     // the consumer gave up: nobody will read the slot
-                        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < MI; ++i) {
+                    const float sa = p.a_scale[min(m0 + wr * WR + i * 16 + li2, p.M - 1)];
+                    acc[j][i] *= sw * sa;
                 }
             }
-        } else {
-            if constexpr (CONV == 2) {                                      // fp8: per-token and per-weight-row scales (fp32)
-                int lane2 = lane;
-                asm volatile("" : "+v"(lane2));                            // keep these addresses out of the K loop's live ranges
-                const int g2 = lane2 >> 4, li2 = lane2 & 15;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int nb = min(cur.n0 + wc * 64 + jj * 16 + 4 * g2, p.N - 4);
-                    const f32x4 sw = *reinterpret_cast<const f32x4*>(p.w_scale + nb);
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) {
-                        const float sa = p.a_scale[min(cur.m0 + wr * WR + i * 16 + li2, p.M - 1)];
-                        acc[jj][i] *= sw * sa;
-                    }
-                }
-            }
-            if (p.lds_epi) gemm_epilogue_lds<MI, true>(p, acc, cur.m0 + wr * WR, cur.n0 + wc * 64, cur.n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
-            else gemm_epilogue<MI>(p, acc, cur.m0 + wr * WR, cur.n0 + wc * 64, cur.n0, wc, g, li);
         }
-        G8_STAMP();                                                         // 3 + 2t: epilogue of segment t issued
-        if (++j >= nseg) break;                                             // uniform
-        cur = nxt;
-        seg_at(min(j + 1, nseg - 1), nxt);
+        if (p.lds_epi) gemm_epilogue_lds<MI, true>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);   // the conv variant has no register to spare for a second path
+        else gemm_epilogue<MI>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, g, li);
+        G8_STAMP();                                                         // 3 + 2t: epilogue of tile t issued
+        v += gridDim.x;
+        if (CONV == 1 || v >= total_tiles) break;                          // uniform
+        m0 = m0n; n0 = n0n;
+        if (v + (int)gridDim.x < total_tiles) tile_origin(v + gridDim.x, m0n, n0n);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the ring's tail DMAs (clamped re-loads) must land before exit
 }
@@ -1104,6 +953,11 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
         // prefill down 322 vs 288: the half-tile moves 1.5x the operand bytes per flop, so a wave's serial LDS-read + DMA-issue
         // time per K tile (620 + 700 cycles, + 340 of waits) exceeds its 1,024 MFMA cycles and the pipes idle 30 % of the loop,
         // which eats what the overlap (two workgroups resident 55-88 % of the time) and the finer tail give back.
+        // Tried (round 5, commit 53a19f3 'experiment: chained stream-K', profiles/r05_streamk_experiment.txt): every workgroup the same number
+        // of K iterations, a tile shared by two workgroups CONTINUED from published accumulators (256 KiB fp32 hand-off, bounded wait,
+        // recomputation as the fallback) -- bit-identical in every test, and 1-14 % SLOWER on every eligible shape (fc1 132.6 -> 143.9 us,
+        // prefill o 109.2 -> 124.6): a K = 1024 tile's loop takes 20.6 us beside neighbours that are all loading and 25.7 us beside
+        // neighbours that are storing, so desynchronised epilogues slow every K loop instead of hiding behind them.  Not kept.
         // Tried (round 2, tools/ab_gemm_split.py): giving the rows of a mostly empty last round (784 tiles = 3.06 rounds) to the
         // 128^2 kernel as a second launch -- fc1 142.5 -> 139.4 us, encoder qkv 88.7 -> 95.3 us, prefill qkv 200.6 -> 198.7 us: a
         // K = 1024 tile of the 128^2 kernel plus the extra launch costs what the idle CUs of the last round cost.  Not kept.
@@ -1122,19 +976,12 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
             attr8 = true;
         }
-        if (conv) { p8.sk_ws = nullptr; p8.sk_flags = nullptr; hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), G8_LDS, s, p8, (int)tiles256); }
+        if (conv) hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), G8_LDS, s, p8, (int)tiles256);
         else {
             // persistent (one workgroup per CU walking the tile list) where tiles are short and the epilogue light:
             // it hides the dispatch and the pipeline fill of every tile after the first, but its epilogue stores must
             // drain before the next tile's counted waits can pass (measured: +8 % at K <= 2048, -2..3 % on long-K or
             // SwiGLU tiles, tools/bench_gemm.py)
-            // Round 5: chained stream-K where a workspace came with the call and the tiles do not fill whole rounds (comment at
-            // gemm8p_kernel): 256-row tiles, one workgroup per CU, every workgroup the same number of K iterations.
-            if (p8.sk_ws && g_q3_option[Q3ASR_OPT_GEMM_STREAMK] && mode != 224 && tiles256 > 256u) {
-                hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(256), dim3(512), G8_LDS, s, p8, (int)tiles256);
-                return;
-            }
-            p8.sk_ws = nullptr; p8.sk_flags = nullptr;
             const bool persist = p.K <= 2048 && p.act != 2;
             // Tile height: a workgroup owns a CU, so a launch costs rounds x tile height; 224-row tiles where that is less
             // (M = 12,480: 196 tiles of 256 rows or 224 of 224 for N = 1,024 -- one round either way, the second 1/8 shorter).
@@ -1179,40 +1026,17 @@ static int gemm_validate(const GemmParams& p, const char* who) {
     return Q3_OK;
 }
 
-// Chained stream-K workspace (gemm8p_kernel): 256 accumulator slots of 256 KiB + one 128-byte flag line per slot.  The caller
-// allocates it, ZEROES it once, and hands the same block to every GEMM call on ONE stream (calls on different streams may run
-// at the same time and need a block each); the library leaves every flag at 0 when a launch ends.
-#define SK_GRID 256
-#define SK_SLOT_BYTES (512L * 32 * 16)
-extern "C" int64_t q3asr_gemm_workspace_bytes(void) { return SK_GRID * (SK_SLOT_BYTES + 128); }
-static bool sk_attach(GemmParams& p, void* workspace, int64_t workspace_bytes) {
-    p.sk_spins = g_q3_option[Q3ASR_OPT_GEMM_SK_RECOMPUTE] ? -1 : G8_SK_SPINS;
-    if (!workspace) return true;
-    if (workspace_bytes < q3asr_gemm_workspace_bytes() || ((uintptr_t)workspace & 127)) return false;
-    p.sk_ws = (float*)workspace;
-    p.sk_flags = (unsigned*)((char*)workspace + SK_GRID * SK_SLOT_BYTES);
-    return true;
-}
-
-extern "C" int q3asr_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
-                                  const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
-                                  void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* workspace, int64_t workspace_bytes,
-                                  void* stream) {
+extern "C" int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
+                               const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
+                               void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream) {
     GemmParams p{};
     p.A = (const bf16*)A; p.lda = lda; p.W = (const bf16*)W; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
     p.bias = bias; p.act = act; p.res = res; p.res_kind = res_kind; p.ldres = ldres; p.res_mod = res_mod;
     p.out = out; p.out_kind = out_kind; p.ldo = ldo; p.row_map = row_map;
     if (int rc = gemm_validate(p, "gemm_bf16")) return rc;
     Q3_REQUIRE(lda % 8 == 0 && lda >= K, "gemm_bf16: lda=%ld must be >= K and a multiple of 8", (long)lda);
-    Q3_REQUIRE(sk_attach(p, workspace, workspace_bytes), "gemm_bf16: workspace of %ld bytes (q3asr_gemm_workspace_bytes() = %ld, 128-byte aligned)", (long)workspace_bytes, (long)q3asr_gemm_workspace_bytes());
     gemm_launch(p, false, (hipStream_t)stream);
     return q3_check_launch("gemm_bf16");
-}
-
-extern "C" int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
-                               const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
-                               void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream) {
-    return q3asr_gemm_bf16_ws(A, lda, W, ldw, M, N, K, bias, act, res, res_kind, ldres, res_mod, out, out_kind, ldo, row_map, nullptr, 0, stream);
 }
 
 // Conv2d k3 s2 p1 over NHWC bf16 as implicit GEMM (encoder.py:155-168,274-275).
@@ -1248,17 +1072,9 @@ extern "C" int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, i
 // v_mfma_f32_16x16x32_fp8_fp8, so per unit of K the MFMA work is that of the bf16 kernel and the LDS / L2 / HBM operand
 // bytes are half.
 // ---------------------------------------------------------------------------
-extern "C" int q3asr_gemm_fp8_ws(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
-                                 int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo,
-                                 void* workspace, int64_t workspace_bytes, void* stream);
 extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
                               int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo,
                               void* stream) {
-    return q3asr_gemm_fp8_ws(A8, lda, a_scale, W8, ldw, w_scale, M, N, K, act, res, res_kind, ldres, out, ldo, nullptr, 0, stream);
-}
-extern "C" int q3asr_gemm_fp8_ws(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
-                                 int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
     GemmParams p{};
     p.A = (const bf16*)A8; p.lda = lda; p.W = (const bf16*)W8; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
     p.act = act; p.res = res; p.res_kind = res_kind; p.ldres = ldres; p.out = out; p.out_kind = 0; p.ldo = ldo;
@@ -1286,8 +1102,6 @@ extern "C" int q3asr_gemm_fp8_ws(const void* A8, int64_t lda, const float* a_sca
     const unsigned tiles224 = (unsigned)((M + 223) / 224) * (unsigned)((N + G2_T - 1) / G2_T);
     const bool t224 = g_gemm_mode == 224 || (g_gemm_mode != 8 && ((tiles224 + 255) / 256) * 224u < ((tiles256 + 255) / 256) * 256u);
     const unsigned tiles8 = t224 ? tiles224 : tiles256;
-    Q3_REQUIRE(sk_attach(p, workspace, workspace_bytes), "gemm_fp8: workspace of %ld bytes (q3asr_gemm_workspace_bytes() = %ld, 128-byte aligned)", (long)workspace_bytes, (long)q3asr_gemm_workspace_bytes());
-    p.sk_ws = nullptr; p.sk_flags = nullptr;              // accepted for symmetry with q3asr_gemm_bf16_ws; the fp8 kernel runs whole tiles (gemm8p_kernel, SKC)
     const bool persist = act != 2 && tiles8 > 256u;
     if (t224) hipLaunchKernelGGL((gemm8p_kernel<2, 3>), dim3(persist ? 256u : tiles8), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles8);
     else hipLaunchKernelGGL(gemm8p_kernel<2>, dim3(persist ? 256u : tiles8), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles8);

@@ -12,38 +12,11 @@ def off_ptr(t, elem_offset: int):
     return C.c_void_p(t.data_ptr() + elem_offset * t.element_size())
 
 
-# Chained stream-K workspaces of the 8-phase GEMM (include/q3asr.h, q3asr_gemm_bf16_ws): one zeroed block per (device, stream) --
-# launches on different streams may overlap and must not share accumulator slots.  64 MiB each; streams beyond the cap run the
-# whole-tile kernels (same bits).
-_gemm_ws: dict = {}
-_GEMM_WS_MAX = 12
-USE_GEMM_WORKSPACE = True
-
-
-def gemm_workspace(device):
-    if not USE_GEMM_WORKSPACE:
-        return None
-    import torch
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    ws = _gemm_ws.get(key)
-    if ws is None:
-        if len(_gemm_ws) >= _GEMM_WS_MAX:
-            return None
-        nbytes = int(_lib.load().q3asr_gemm_workspace_bytes())
-        ws = _gemm_ws[key] = torch.zeros((nbytes,), dtype=torch.uint8, device=device)
-    return ws
-
-
-def release_gemm_workspaces() -> None:
-    _gemm_ws.clear()
-
-
 def gemm(A, W, M, N, K, out, *, lda=None, ldw=None, bias=None, act=0, res=None, res_kind=0, ldres=0, res_mod=0,
          out_fp32=False, ldo=None, row_map=None):
-    ws = gemm_workspace(out.device) if ((M + 255) // 256) * ((N + 255) // 256) > 256 else None      # only launches of more than 256 tiles use it
-    call("q3asr_gemm_bf16_ws", ptr(A), lda if lda is not None else K, ptr(W), ldw if ldw is not None else K, M, N, K,
+    call("q3asr_gemm_bf16", ptr(A), lda if lda is not None else K, ptr(W), ldw if ldw is not None else K, M, N, K,
          ptr(bias), act, ptr(res), res_kind, ldres, res_mod, ptr(out), 1 if out_fp32 else 0,
-         ldo if ldo is not None else (N // 2 if act == 2 else N), ptr(row_map), ptr(ws), 0 if ws is None else ws.numel(), sp())
+         ldo if ldo is not None else (N // 2 if act == 2 else N), ptr(row_map), sp())
 
 
 def conv_weight_chunked(w):
@@ -64,10 +37,8 @@ def conv3x3s2(x, imgs, Hin, Win, Cin, w, Cout, bias, act, out, out_fp32=False):
 
 def gemm_fp8(A8, a_scale, W8, w_scale, M, N, K, out, act=0, res=None, ldo=None):
     """fp8 x fp8 GEMM (csrc/gemm.hip, q3asr_gemm_fp8): bytes [M][K] x bytes [N][K] -> bf16; res: bf16 residual (MLX add)."""
-    ws = gemm_workspace(out.device) if ((M + 255) // 256) * ((N + 255) // 256) > 256 else None
-    call("q3asr_gemm_fp8_ws", ptr(A8), K, ptr(a_scale), ptr(W8), K, ptr(w_scale), M, N, K, act, ptr(res), 2 if res is not None else 0,
-         N if res is not None else 0, ptr(out), ldo if ldo is not None else (N // 2 if act == 2 else N), ptr(ws),
-         0 if ws is None else ws.numel(), sp())
+    call("q3asr_gemm_fp8", ptr(A8), K, ptr(a_scale), ptr(W8), K, ptr(w_scale), M, N, K, act, ptr(res), 2 if res is not None else 0,
+         N if res is not None else 0, ptr(out), ldo if ldo is not None else (N // 2 if act == 2 else N), sp())
 
 
 def rmsnorm_fp8(x, w, y8, scale, M, D, eps):

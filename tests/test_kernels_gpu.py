@@ -304,99 +304,6 @@ def test_gemm_8phase_is_stable_under_load(dev, mode):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(12480, 4096, 1024, "gelu"), (12480, 3072, 1024, "bias"), (13056, 4096, 2048, "plain"),
-                                       (13056, 2048, 2048, "res16"), (13056, 2048, 6144, "res16"), (13056, 12288, 2048, "swiglu"),
-                                       (4396, 4096, 512, "res32"), (2050, 8448, 256, "plain"), (6000, 3000, 384, "gelu")])
-def test_gemm_chained_streamk_is_bit_identical(dev, M, N, K, epi):
-    """Round 5: the 8-phase kernel's chained stream-K form (q3asr_gemm_bf16_ws; csrc/gemm.hip) against the whole-tile kernels
-    on the encoder / prefill shapes at batch 32 and on ragged shapes (M, N not multiples of 256; K = 256: one iteration pair per
-    tile ... 6,144: 48): a tile that two workgroups share has its MFMA chains CONTINUED from published accumulators, so every
-    arm must give the same bits -- (a) whole tiles (option off), (b) stream-K, (c) stream-K with every hand-off abandoned and the
-    tile's head recomputed by the consumer (test hook; the path a consumer takes when its producer is not resident in time),
-    (d) stream-K again on the same workspace: every flag is back at 0 after each launch, no memset between launches."""
-    from qwen3_asr_mlx_amd import _lib, ops
-    lib = _lib.load()
-    A = rnd((M, K), dev, 140, 1.0)
-    W = rnd((N, K), dev, 141, 1.0 / math.sqrt(K))
-    bias = rnd((N,), dev, 142, 0.5, torch.float32)
-    hb = rnd((M, N), dev, 143) if epi == "res16" else None
-    h0 = rnd((M, N), dev, 144, 1.0, torch.float32) if epi == "res32" else None
-
-    def run():
-        if epi == "res32":
-            o = h0.clone()
-            ops.gemm(A, W, M, N, K, o, bias=bias, res=o, res_kind=1, ldres=N, out_fp32=True)
-        elif epi == "res16":
-            o = hb.clone()                                             # in place, as the prefill's o / down projections run
-            ops.gemm(A, W, M, N, K, o, res=o, res_kind=2, ldres=N)
-        elif epi == "swiglu":
-            o = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev)
-            ops.gemm(A, W, M, N, K, o, act=2)
-        else:
-            o = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-            ops.gemm(A, W, M, N, K, o, bias=None if epi == "plain" else bias, act=1 if epi == "gelu" else 0)
-        return o
-
-    ws = ops.gemm_workspace(dev)
-    assert ws is not None and ws.numel() == lib.q3asr_gemm_workspace_bytes()
-    flags = ws[256 * 512 * 32 * 16:].view(torch.int32)
-    outs = {}
-    try:
-        _lib.call("q3asr_gemm_force_kernel", 8)
-        lib.q3asr_set_option(3, 0)
-        outs["whole tiles"] = run()
-        lib.q3asr_set_option(3, 1)
-        outs["stream-K"] = run()
-        torch.cuda.synchronize()
-        assert int(flags.abs().sum()) == 0
-        lib.q3asr_set_option(4, 1)
-        outs["stream-K, heads recomputed"] = run()
-        torch.cuda.synchronize()
-        assert int(flags.abs().sum()) == 0
-        lib.q3asr_set_option(4, 0)
-        outs["stream-K again"] = run()
-        _lib.call("q3asr_gemm_force_kernel", 128)
-        outs["128^2 kernel"] = run()
-    finally:
-        lib.q3asr_set_option(3, 1)
-        lib.q3asr_set_option(4, 0)
-        _lib.call("q3asr_gemm_force_kernel", 0)
-    torch.cuda.synchronize()
-    assert int(flags.abs().sum()) == 0
-    for name, o in outs.items():
-        assert torch.equal(o, outs["whole tiles"]), name
-
-
-def test_gemm_chained_streamk_on_two_streams_at_once(dev):
-    """Two stream-K launches in flight on two streams (each with its own workspace: ops.gemm_workspace keys them by stream): the
-    hardware may leave workgroups of either launch undispatched while residents of the other wait for a hand-off -- the bounded
-    wait and the recomputation are what guarantee completion.  Twenty pairs; every result bit-identical to the whole-tile run."""
-    from qwen3_asr_mlx_amd import _lib, ops
-    lib = _lib.load()
-    M, N, K = 6144, 6144, 1024                                        # 576 tiles = 2.25 rounds
-    A = [rnd((M, K), dev, 150 + i, 1.0) for i in range(2)]
-    W = [rnd((N, K), dev, 152 + i, 1.0 / math.sqrt(K)) for i in range(2)]
-    lib.q3asr_set_option(3, 0)
-    try:
-        ref = []
-        for i in range(2):
-            o = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-            ops.gemm(A[i], W[i], M, N, K, o)
-            ref.append(o)
-    finally:
-        lib.q3asr_set_option(3, 1)
-    torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    outs = [[torch.empty((M, N), dtype=torch.bfloat16, device=dev) for _ in range(20)] for _ in range(2)]
-    for r in range(20):
-        for i, st in enumerate(streams):
-            with torch.cuda.stream(st):
-                ops.gemm(A[i], W[i], M, N, K, outs[i][r])
-    torch.cuda.synchronize()
-    bad = [(i, r) for i in range(2) for r in range(20) if not torch.equal(outs[i][r], ref[i])]
-    assert not bad, bad
-
-
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1000, 768, 1024), (4396, 2048, 2048), (130, 1024, 6144)])
 def test_gemm_fp8_on_the_fp8_mfma(dev, M, N, K):
     """q3asr_gemm_fp8: per-token quantised activations x per-row quantised weights on v_mfma_f32_16x16x32_fp8_fp8 against
