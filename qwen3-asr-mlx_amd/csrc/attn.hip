@@ -49,6 +49,8 @@ struct AttnParams {
                                            // a multi-token call on a non-empty cache); the segment then has seg_len + seg_k_off keys
     int group;                             // query heads per kv head
     float scale;
+    int n_qt, n_heads;                     // query tiles per segment (grid), query heads: the 1-D grid is decoded in the kernel
+    int xcd_order;
 };
 
 // Occupancy: 3 workgroups per CU (round 3; the compiler's free choice was 170 VGPRs = 2): 86-93 -> 76-77 us per prefill layer at
@@ -60,8 +62,27 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KV_TILE * HD * 2];
     char* sK = smem;
     char* sV = smem + KV_TILE * HD * 2;
-    // causal: a query tile's work grows with its index -- dispatch the heavy tiles of a (segment, head) first
-    const int seg = blockIdx.z, head = blockIdx.y, qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    // Round 5: XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs, and with the grid (query tile, head, segment)
+    // of rounds 1-4 the 14 workgroups that read ONE kv head's K/V (7 query tiles x 2 query heads of a 408-token prompt) sat on 7-8
+    // different XCDs: every private L2 fetched the same 208 KB again from beyond it (r04 PMC: 341 MB fetched for 160 MB) and a
+    // tile's loads paid that latency.  The 1-D grid is remapped so that an XCD gets a contiguous chunk of the order
+    // (segment, kv head, query tile heavy-first, query head of the group): the workgroups that share K/V run on one XCD, next to
+    // each other in time.  Same arithmetic per workgroup: same bits.
+    int seg, head, qt;
+    if (p.xcd_order) {
+        const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
+        const int per_kv = p.n_qt * p.group, per_seg = per_kv * (p.n_heads / p.group);
+        seg = (int)(L / (unsigned)per_seg);
+        const int r_seg = (int)(L % (unsigned)per_seg);
+        const int kvh = r_seg / per_kv, w = r_seg % per_kv;
+        head = kvh * p.group + w % p.group;
+        qt = CAUSAL ? p.n_qt - 1 - w / p.group : w / p.group;          // causal: a query tile's work grows with its index -- heavy tiles first
+    } else {                                                           // the order of rounds 1-4 (A/B: q3asr_set_option(Q3ASR_OPT_ATTN_XCD_ORDER, 0))
+        const int b = (int)blockIdx.x;
+        qt = CAUSAL ? p.n_qt - 1 - b % p.n_qt : b % p.n_qt;
+        head = (b / p.n_qt) % p.n_heads;
+        seg = b / (p.n_qt * p.n_heads);
+    }
     const int len = p.seg_len[seg];
     if (qt * 64 >= len) return;
     const int koff = p.seg_k_off ? p.seg_k_off[seg] : 0;   // query row i sits at position koff + i and sees keys 0 .. koff + i
@@ -261,7 +282,9 @@ extern "C" int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, co
     p.kv_seg_off = (const long*)kv_seg_off; p.kv_head_stride = kv_head_stride; p.kv_row_stride = kv_row_stride;
     p.O = (bf16*)O; p.o_stride = o_stride; p.seg_q_start = seg_q_start; p.seg_len = seg_len; p.seg_k_off = seg_k_off;
     p.group = n_heads / n_kv_heads; p.scale = scale;
-    dim3 grid((max_len + 63) / 64, n_heads, n_segs), blk(256);
+    p.n_qt = (max_len + 63) / 64; p.n_heads = n_heads; p.xcd_order = g_q3_option[Q3ASR_OPT_ATTN_XCD_ORDER];
+    Q3_REQUIRE((int64_t)p.n_qt * n_heads * n_segs < (1LL << 31), "attn_fwd: grid of %d x %d x %d workgroups", p.n_qt, n_heads, n_segs);
+    dim3 grid((unsigned)(p.n_qt * n_heads * n_segs)), blk(256);
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 64 && !causal) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, blk, 0, s, p);
     else if (head_dim == 128 && causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, blk, 0, s, p);

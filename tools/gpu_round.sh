@@ -51,8 +51,10 @@ for step in "$@"; do
     tests_s)      run 600 $O/${TAG}_tests_s.log python3 -m pytest $R/tests/test_sampling_gpu.py $R/tests/test_e2e_gpu.py -m gpu -q -x ; tail -5 $O/${TAG}_tests_s.log ;;
     tests_fp8)    run 900 $O/${TAG}_fp8.log python3 -m pytest $R/tests/test_parity_gpu.py -m gpu -q -s -k "fp8_mfma or one_full_size_layer" ; grep -v '^\[parity\]' $O/${TAG}_fp8.log | tail -30 ;;
     bench_gemm)   run 400 $O/${TAG}_bench_gemm.log python3 $R/tools/bench_gemm.py ${BENCH_GEMM_ARGS:-5 8,2} ; cat $O/${TAG}_bench_gemm.log ;;
+    longform)     run 500 $O/${TAG}_longform.log python3 $R/tools/longform_variants.py ${LONGFORM_ARGS:-fp8 128} ; grep -v amdgpu.ids $O/${TAG}_longform.log ;;
     tests_gemm)   run 600 $O/${TAG}_tests_gemm.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k gemm ; tail -8 $O/${TAG}_tests_gemm.log ;;
     admit_cost)   run 300 $O/${TAG}_admit_cost.log python3 $R/tools/admit_cost.py ; grep "k=" $O/${TAG}_admit_cost.log ;;
+    ab_attn)      run 300 $O/${TAG}_ab_attn.log python3 $R/tools/ab_attn.py ${AB_ATTN_ARGS:-3} ; grep -v amdgpu.ids $O/${TAG}_ab_attn.log ;;
     tests_attn)   run 600 $O/${TAG}_tests_attn.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k attn ; tail -5 $O/${TAG}_tests_attn.log ;;
     serve)        run 500 $O/${TAG}_serve32.log python3 $R/tools/bench_serve.py 32 25,60,90,120 6 ; tail -1 $O/${TAG}_serve32.log > $O/${TAG}_serve32.json; grep offered $O/${TAG}_serve32.log | cut -c1-200
                   run 400 $O/${TAG}_serve64.log python3 $R/tools/bench_serve.py 64 90,130 6 ; tail -1 $O/${TAG}_serve64.log > $O/${TAG}_serve64.json; grep offered $O/${TAG}_serve64.log | cut -c1-200 ;;
