@@ -133,6 +133,9 @@ int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, const void* V
                    const int32_t* seg_q_start, const int32_t* seg_len, const int32_t* seg_k_off, int n_segs, int max_len,
                    int max_klen, int n_heads, int n_kv_heads, int head_dim, int causal, float scale, void* stream);
 
+/* Diagnostic: workgroup `workgroup` of the following attn_fwd launches records wall_clock64() stamps into buf (64 x u64 device memory; NULL = off) */
+int q3asr_attn_set_stamp(void* buf, int workgroup);
+
 /* ---- generate.py:20-81  prepare_inputs ------------------------------------------------------- */
 /* E: embedding table with V rows; enc: n_enc encoder rows.  Index vectors are device-resident and cannot be validated
  * by the host: a token id outside [0, V) or an encoder row >= n_enc yields a zero row, never an out-of-bounds read. */

@@ -33,6 +33,7 @@ _SIGS = {
     "q3asr_layernorm_f32_bf16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "q3asr_rmsnorm_bf16": [_vp, _i64, _vp, _vp, _i64, _vp, _i, _i, _f, _vp],
     "q3asr_attn_fwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "q3asr_attn_set_stamp": [_vp, _i],
     "q3asr_embed_merge": [_vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "q3asr_qk_norm_rope_kv": [_vp, _i, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "q3asr_skinny3_gemm": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp],

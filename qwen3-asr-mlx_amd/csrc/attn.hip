@@ -16,6 +16,7 @@
 //                      -> O^T[d=16dt+4g+r][q=li]: the softmax rescale is lane-local.
 // Softmax in fp32; P rounded to bf16 for the PV MFMA; the row sum uses unrounded P.
 #include "common.h"
+#include <type_traits>
 
 #define KV_TILE 64
 
@@ -51,6 +52,7 @@ struct AttnParams {
     float scale;
     int n_qt, n_heads;                     // query tiles per segment (grid), query heads: the 1-D grid is decoded in the kernel
     int xcd_order;
+    unsigned long long* stamp; int stamp_wg;   // diagnostic (q3asr_attn_set_stamp): workgroup stamp_wg records wall_clock64() at its phase boundaries
 };
 
 // Occupancy: 3 workgroups per CU (round 3; the compiler's free choice was 170 VGPRs = 2): 86-93 -> 76-77 us per prefill layer at
@@ -62,12 +64,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KV_TILE * HD * 2];
     char* sK = smem;
     char* sV = smem + KV_TILE * HD * 2;
-    // Round 5: XCD-aware order.  Workgroups are dealt round-robin over the 8 XCDs, and with the grid (query tile, head, segment)
-    // of rounds 1-4 the 14 workgroups that read ONE kv head's K/V (7 query tiles x 2 query heads of a 408-token prompt) sat on 7-8
-    // different XCDs: every private L2 fetched the same 208 KB again from beyond it (r04 PMC: 341 MB fetched for 160 MB) and a
-    // tile's loads paid that latency.  The 1-D grid is remapped so that an XCD gets a contiguous chunk of the order
-    // (segment, kv head, query tile heavy-first, query head of the group): the workgroups that share K/V run on one XCD, next to
-    // each other in time.  Same arithmetic per workgroup: same bits.
+    // Round 5: XCD-aware order (p.xcd_order; the launcher sets it for the bidirectional = encoder launches).  Workgroups are dealt
+    // round-robin over the 8 XCDs, so with the plain (query tile, head, segment) grid the workgroups that read ONE kv head's K/V sit
+    // on different XCDs and every private L2 fetches it again.  The 1-D grid is remapped so that an XCD gets a contiguous chunk of
+    // the order (segment, kv head, query tile, query head of the group).  Same arithmetic per workgroup: same bits.  Measured
+    // (tools/ab_attn.py, batch 32): encoder windows 35.7 -> 32.5 us per layer; the causal prefill 72.1 -> 73.9 us -- its K/V
+    // loads are not what a key tile waits for (profiles/r05_attention.txt has the stamped timeline) -- so it keeps the grid order.
     int seg, head, qt;
     if (p.xcd_order) {
         const unsigned L = xcd_remap(blockIdx.x, gridDim.x);
@@ -89,6 +91,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     const int klen = len + koff;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
+    int n_stamp = 0;
+    const bool stamping = p.stamp != nullptr && (int)blockIdx.x == p.stamp_wg;                // uniform
+#define ATT_STAMP() do { if (stamping && tid == 0 && n_stamp < 63) p.stamp[1 + n_stamp++] = wall_clock64(); } while (0)
+    ATT_STAMP();                                                                            // 0: entry
     const int q_abs = qt * 64 + wave * 16 + li;
     const int q_eff = min(q_abs, len - 1);
     const long qrow = (long)p.seg_q_start[seg] + q_eff;
@@ -108,6 +114,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = p.scale * 1.4426950408889634f;      // scale * log2(e): the softmax exponent in base 2 (below)
 
     const int n_tiles = CAUSAL ? (min(klen, koff + qt * 64 + 64) + KV_TILE - 1) / KV_TILE : (klen + KV_TILE - 1) / KV_TILE;   // koff = 0: qt + 1
     // K and V tile: KV_TILE*CPR 16-byte chunks each, 256 threads; the next tile's chunks are loaded into registers while
@@ -150,15 +157,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
         }
         if (kt + 1 < n_tiles) fetch(kt + 1);
         __syncthreads();
+        ATT_STAMP();                                         // 1 + 4 kt: tile staged (waited for its loads, written to LDS, both barriers)
 
         // ---- S^T = K Q^T.  Round 4: k-step outer, the four key tiles' fragments read as one group in front of their four
         // MFMAs.  Written key-tile outer, hipcc (at the 170-VGPR cap of three workgroups per CU) emitted ds_read ->
         // s_waitcnt lgkmcnt(0) -> MFMA sixteen times in a row, the four MFMAs of a key tile back to back on ONE accumulator:
         // 32 exposed LDS round trips and 12 dependent-MFMA stalls per key tile and wave (with PV below), which is what the
         // stamps of round 3 called "latency-bound".  Each accumulator still sees its k-steps in ascending order: same bits.
-        f32x4 s[4];
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) s[k4] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 s[4];                                          // first k-step: accumulator operand = the inline constant 0 (no 16 v_mov per tile)
         bf16x8 kf[2][4];                                     // the next k-step's fragments are requested before this one's MFMAs
         auto read_k = [&](int ks, bf16x8 (&f)[4]) {
 #pragma unroll
@@ -171,51 +177,59 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
             if (ks + 1 < KS) read_k(ks + 1, kf[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) s[k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][k4], qf[ks], s[k4], 0, 0, 0);
+            for (int k4 = 0; k4 < 4; ++k4)
+                s[k4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks & 1][k4], qf[ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[k4], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- mask + online softmax (row = query li, spread over the 4 lane groups)
         // Only the last key tile(s) of a query tile can hold keys beyond the sequence or above the diagonal (mask_from above):
         // the mask runs there alone (uniform branch).
-        float tmax = -INFINITY;
-        if (kt >= mask_from) {
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * KV_TILE + 16 * k4 + 4 * g + r;
-                    const bool ok = key < klen && (!CAUSAL || key <= q_eff + koff);
-                    const float v = ok ? s[k4][r] * p.scale : -INFINITY;
-                    s[k4][r] = v;
-                    tmax = fmaxf(tmax, v);
-                }
-        } else {
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = s[k4][r] * p.scale;
-                    s[k4][r] = v;
-                    tmax = fmaxf(tmax, v);
-                }
-        }
-        tmax = lane_xor16_max(tmax);                     // = fmaxf(tmax, tmax[lane ^ 16]) without the LDS crossbar (common.h)
-        tmax = lane_xor32_max(tmax);
-        const float m_new = fmaxf(m_run, tmax);          // finite: key 0 is visible to every query
-        const float alpha = __expf(m_run - m_new);       // m_run = -inf on the first tile -> 0
-        float psum = 0.f;
+        // Round 5: the softmax runs on the RAW scores in the base-2 domain: exp(scale (s - m)) = 2^(c s - c m), c = scale log2(e)
+        // (scale > 0, so the maximum of the raw scores is the maximum of the scaled ones).  One v_fma + one v_exp per score in
+        // place of v_mul (scale), v_sub, v_mul (log2 e inside __expf), v_exp: 33 fewer VALU instructions of the ~187 a wave issues per
+        // key tile, and the loop is VALU-ISSUE-bound -- a wave64 VALU instruction takes ~4.3 cycles on this part (r04 PMC), so a key
+        // tile's 170 + 17 transcendental instructions are ~870 cycles of issue against 512 cycles of MFMA (profiles/r05_attention.txt).
+        ATT_STAMP();                                         // 2 + 4 kt: S = K Q^T done
+        // The whole softmax is written once and instantiated in both branches: the scores are only READ after the MFMAs (with the
+        // mask applied in place, the join of the two branches cost the common path 16 register copies per tile).
+        float alpha;
         bf16x8 pf[2];
+        auto softmax = [&](auto masked) {
+            float tmax = -INFINITY;
+            float sv[4][4];
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4)
+            for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __expf(s[k4][r] - m_new);
-                psum += pv;
-                pf[k4 >> 1][(k4 & 1) * 4 + r] = f2bf(pv);
-            }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[k4][r];
+                    if constexpr (decltype(masked)::value) {
+                        const int key = kt * KV_TILE + 16 * k4 + 4 * g + r;
+                        v = (key < klen && (!CAUSAL || key <= q_eff + koff)) ? v : -INFINITY;
+                    }
+                    sv[k4][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = lane_xor16_max(tmax);                 // = fmaxf(tmax, tmax[lane ^ 16]) without the LDS crossbar (common.h)
+            tmax = lane_xor32_max(tmax);
+            const float m_new = fmaxf(m_run, tmax);      // raw-score units; finite: key 0 is visible to every query
+            alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);               // m_run = -inf on the first tile -> 0
+            const float mc = -m_new * c2;
+            float psum = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sv[k4][r], c2, mc));   // masked scores are -inf: 2^-inf = 0
+                    psum += pv;
+                    pf[k4 >> 1][(k4 & 1) * 4 + r] = f2bf(pv);
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+        };
+        if (kt >= mask_from) softmax(std::true_type{});
+        else softmax(std::false_type{});
 
+        ATT_STAMP();                                         // 3 + 4 kt: softmax done
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] *= alpha;
         // ---- O^T += V^T P^T
@@ -247,7 +261,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
             for (int dd = 0; dd < 4; ++dd) o[d0 + dd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u[q & 1][dd].v, pf[c], o[d0 + dd], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        ATT_STAMP();                                         // 4 + 4 kt: O += P V issued
     }
+    ATT_STAMP();                                             // loop done (the last tile's P V included)
+    if (stamping && tid == 0) p.stamp[0] = (unsigned long long)n_stamp | ((unsigned long long)qt << 32);
     float l_tot = lane_xor16_sum(l_run);
     l_tot = lane_xor32_sum(l_tot);
     // the output addresses are rebuilt here from an opaque copy of the thread id: hoisted above the key loop they stayed live
@@ -268,6 +285,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
+static unsigned long long* g_attn_stamp = nullptr;
+static int g_attn_stamp_wg = 0;
+// Diagnostic: workgroup `wg` (blockIdx.x) of the following attn_fwd launches writes wall_clock64() stamps (100 MHz) to buf (64 x u64 device
+// memory): [0] = count | query tile << 32, then entry and per key tile "staged / S done / softmax done / PV issued", then "loop done".
+extern "C" int q3asr_attn_set_stamp(void* buf, int wg) { g_attn_stamp = (unsigned long long*)buf; g_attn_stamp_wg = wg; return 0; }
+
 extern "C" int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, const void* V, const int64_t* kv_seg_off,
                               int64_t kv_head_stride, int64_t kv_row_stride, void* O, int64_t o_stride,
                               const int32_t* seg_q_start, const int32_t* seg_len, const int32_t* seg_k_off, int n_segs, int max_len,
@@ -282,7 +305,10 @@ extern "C" int q3asr_attn_fwd(const void* Q, int64_t q_stride, const void* K, co
     p.kv_seg_off = (const long*)kv_seg_off; p.kv_head_stride = kv_head_stride; p.kv_row_stride = kv_row_stride;
     p.O = (bf16*)O; p.o_stride = o_stride; p.seg_q_start = seg_q_start; p.seg_len = seg_len; p.seg_k_off = seg_k_off;
     p.group = n_heads / n_kv_heads; p.scale = scale;
-    p.n_qt = (max_len + 63) / 64; p.n_heads = n_heads; p.xcd_order = g_q3_option[Q3ASR_OPT_ATTN_XCD_ORDER];
+    // XCD-aware order for the encoder's windows (32.5 vs 35.7 us per layer at batch 32); the causal prefill keeps the grid order of
+    // rounds 1-4, where the same remap measured 73.9 vs 72.1 us (tools/ab_attn.py, profiles/r05_attention.txt)
+    p.n_qt = (max_len + 63) / 64; p.n_heads = n_heads; p.xcd_order = g_q3_option[Q3ASR_OPT_ATTN_XCD_ORDER] && !causal;
+    p.stamp = g_attn_stamp; p.stamp_wg = g_attn_stamp_wg;
     Q3_REQUIRE((int64_t)p.n_qt * n_heads * n_segs < (1LL << 31), "attn_fwd: grid of %d x %d x %d workgroups", p.n_qt, n_heads, n_segs);
     dim3 grid((unsigned)(p.n_qt * n_heads * n_segs)), blk(256);
     hipStream_t s = (hipStream_t)stream;

@@ -19,6 +19,7 @@ def bench(name, call, out):
     for rnd in range(6):
         for arm in (1, 0):
             lib.q3asr_set_option(OPT, arm)
+            state["i"] = 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):
