@@ -72,7 +72,7 @@ int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int 
                     const float* bias, int act, const void* res, int res_kind, int64_t ldres, int res_mod,
                     void* out, int out_kind, int64_t ldo, const int32_t* row_map, void* stream);
 /* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 64 = 64x64 tile, 128 = 128x128 tile, 8 = 256x256 8-phase LDS-DMA
- * pipeline where its preconditions hold, 224 = the same pipeline on 224x256 tiles).  All kernels give bit-identical results. */
+ * pipeline where its preconditions hold, 224 / 208 = the same pipeline on 224x256 / 208x256 tiles).  All kernels give bit-identical results. */
 int q3asr_gemm_force_kernel(int mode);
 /* Diagnostic: 0 = every sub-tile of the 8-phase kernels takes the general (bounds-tested) epilogue, 1 = interior sub-tiles take the short one (default). Same bits either way; returns the previous setting. Used by tools/ab_gemm_epilogue.py */
 int q3asr_gemm_set_interior(int on);

@@ -16,6 +16,7 @@
 // Bound: MFMA (dense bf16 peak 2.5 PFLOP/s); algorithmic flops = 2*M*N*K.
 #include "common.h"
 #include <atomic>
+#include <type_traits>
 #include <stdlib.h>
 
 #define BM 128
@@ -47,8 +48,8 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + (
 
 // Epilogue shared by both GEMM kernels.  A lane holds, for accumulator tile (j, i): output row
 // m = m_base + 16 i + li and the 4 consecutive columns n = n_base + 16 j + 4 g + r.
-template <int MI, int NJ = 4>   // NJ: 16-column tiles per wave (4: 64 columns; 2: the 64x64-tile kernel's 32)
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NJ][MI], int m_base, int n_base, int n0, int wn,
+template <int MI, int NJ = 4, int MIA = MI>   // NJ: 16-column tiles per wave (4: 64 columns; 2: the 64x64-tile kernel's 32); MIA: row blocks the array holds (>= MI)
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[NJ][MIA], int m_base, int n_base, int n0, int wn,
                                               int g, int li) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -117,8 +118,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // (read as whole rows too) after it; arithmetic and rounding points are those of gemm_epilogue, so results are bit-identical.
 // Preconditions (checked on the host, else gemm_epilogue): N % 8 == 0, ldo / ldres multiples of 8, 16-byte aligned bases.
 // ---------------------------------------------------------------------------
-template <int MI = 8, bool INTERIOR = true>   // MI: 16-row blocks per wave, 8 (128 rows) or 7 (the 224-row tile's 112); INTERIOR: compile the interior-tile path
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][MI], int m_base, int n_base, int n0, int wn,
+template <int MI = 8, int MIA = MI>   // MI: 16-row blocks per wave: 8 (128 rows), 7 (112) or 6 (96: the second wave row of a 208-row tile); MIA: blocks the array holds
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][MIA], int m_base, int n_base, int n0, int wn,
                                                   char* st, int lane) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // lane-derived addresses are recomputed here from an opaque copy of the lane id: hoisted above the K loop they would
@@ -128,7 +129,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     if (p.act == 2) {                                                     // SwiGLU: 16 rows x 32 output columns per block (64-byte rows)
         const int n_out0 = (n0 >> 1) + wn * 32;
         const int rr = lane >> 2, rc = lane & 3;
-        if (INTERIOR && p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map) {   // interior sub-tile: see the bf16 path below
+        if (p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map) {   // interior sub-tile: see the bf16 path below
             const unsigned voff = (unsigned)rr * (unsigned)p.ldo + (unsigned)(n_out0 + 8 * rc);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -182,7 +183,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         // and has no row map stores through a uniform row pointer + one 32-bit lane offset, without per-row bound tests and
         // 64-bit address chains: a wave64 VALU instruction takes ~4 cycles on this part (tools/pmc_kernel.sh), and the general
         // path spends a few hundred of them per tile on addresses.  Same values, same rounding points.
-        if (INTERIOR && p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {
+        if (p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {
             const unsigned voff = (unsigned)(lane >> 3) * (unsigned)p.ldo + (unsigned)(n_base + 8 * rc);
             const unsigned roff = (unsigned)(lane >> 3) * (unsigned)p.ldres + (unsigned)(n_base + 8 * rc);
             f32x4 bv[4];
@@ -263,7 +264,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     // fp32 out (+ optional fp32 residual): 16 rows x 64 columns per block (256-byte rows), one block in flight
     const int rc = lane & 15;
     const int n = n_base + 4 * rc;
-    if (INTERIOR && p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {   // interior sub-tile: see the bf16 path above
+    if (p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {   // interior sub-tile: see the bf16 path above
         const unsigned voff = (unsigned)(lane >> 4) * (unsigned)p.ldo + (unsigned)(n_base + 4 * rc);
         const unsigned roff = (unsigned)(lane >> 4) * (unsigned)p.ldres + (unsigned)(n_base + 4 * rc);
         f32x4 bv[4];
@@ -726,8 +727,8 @@ __device__ __forceinline__ void g8_read_b(const G8Ctx& c, bf16x8 (&bf)[2][2]) {
         bf[jj][1] = *reinterpret_cast<const bf16x8*>(b + ((c.rdB + jj * 2048) ^ 64u));
     }
 }
-template <int MH, int NH, bool F8 = false, int MI1 = 4>   // MI1: 16-row tiles in the second M half of a wave (4, or 3: 224-row tile)
-__device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][4 + MI1], const bf16x8 (&af)[4][2], const bf16x8 (&bf)[2][2]) {
+template <int MH, int NH, bool F8 = false, int MI1 = 4, int MIA = 4 + MI1>   // MI1: 16-row tiles in the second M half of a wave (4; 3: 112-row wave row; 2: 96-row); MIA: array rows
+__device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][MIA], const bf16x8 (&af)[4][2], const bf16x8 (&bf)[2][2]) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -752,24 +753,24 @@ __device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][4 + MI1], const bf16x8 (
 
 // One phase.  PH = g & 7; `tile` = K tile whose half-tile S[g+7] is issued ((g + 7) >> 2).
 // b0cur: B0 fragments of the K tile being computed; b0nxt: filled in phase 3 (mod 4) for the next K tile.
-template <int PH, int CONV, int MI1 = 4>
-__device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0, int tn0, f32x4 (&acc)[4][4 + MI1], bf16x8 (&af)[4][2],
+template <int PH, int CONV, int MI1 = 4, int MIA = 4 + MI1, int WRS = 16 * (4 + MI1)>   // WRS: rows between the two wave rows' images (rows of wave row 0)
+__device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0, int tn0, f32x4 (&acc)[4][MIA], bf16x8 (&af)[4][2],
                                          bf16x8 (&b1)[2][2], bf16x8 (&b0cur)[2][2], bf16x8 (&b0nxt)[2][2]) {
     constexpr int RS = (PH + 1) & 7, RK = (PH + 1) & 3;          // slot / kind read in this phase
     if constexpr (RK == 1) g8_read_a<RS>(c, af);
     else if constexpr (RK == 3) g8_read_a<RS, MI1>(c, af);
     else if constexpr (RK == 2) g8_read_b<RS>(c, b1);
     else g8_read_b<RS>(c, b0nxt);
-    g8_issue<(PH + 7) & 3, (PH + 7) & 7, CONV, 16 * (4 + MI1)>(c, issue_tile, tm0, tn0);
+    g8_issue<(PH + 7) & 3, (PH + 7) & 7, CONV, WRS>(c, issue_tile, tm0, tn0);
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     G8_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    if constexpr ((PH & 3) == 0) g8_mfma<0, 0, CONV == 2, MI1>(acc, af, b0cur);
-    else if constexpr ((PH & 3) == 1) g8_mfma<0, 1, CONV == 2, MI1>(acc, af, b1);
-    else if constexpr ((PH & 3) == 2) g8_mfma<1, 1, CONV == 2, MI1>(acc, af, b1);
-    else g8_mfma<1, 0, CONV == 2, MI1>(acc, af, b0cur);
+    if constexpr ((PH & 3) == 0) g8_mfma<0, 0, CONV == 2, MI1, MIA>(acc, af, b0cur);
+    else if constexpr ((PH & 3) == 1) g8_mfma<0, 1, CONV == 2, MI1, MIA>(acc, af, b1);
+    else if constexpr ((PH & 3) == 2) g8_mfma<1, 1, CONV == 2, MI1, MIA>(acc, af, b1);
+    else g8_mfma<1, 0, CONV == 2, MI1, MIA>(acc, af, b0cur);
     __builtin_amdgcn_s_setprio(0);
     G8_BAR();
 }
@@ -782,10 +783,16 @@ __device__ __forceinline__ void g8_phase(const G8Ctx& c, int issue_tile, int tm0
 // of its four MFMA tiles; the half-tile images keep their 128-row slots, the unused 16 rows per wave row are staged and ignored).
 // Round 3: M = 12,480 / 13,056 rows make 196 / 408 / 784 / 816 tiles of 256 rows on 256 CUs -- rounds that are 77-80 % full --
 // and 224 / 472 / 896 / 944 tiles of 224: the same number of rounds, each 0.875 of the work (gemm_launch picks per shape).
-template <int CONV, int MI1 = 4>      // CONV 0: plain bf16, 1: implicit-GEMM conv (bf16), 2: plain fp8 (e4m3 x e4m3, scales in the epilogue)
+// Round 5: MI1B < MI1 gives the two wave rows different heights: MI1 = 3, MI1B = 2 is a 208-row tile (112 + 96 rows).  At M = 12,480 /
+// 13,056 rows every 8-phase launch of the encoder and the prefill runs the same number of ROUNDS on 208-row tiles as on 224-row
+// ones (60 / 63 row tiles against 56 / 59: N = 1,024 -> 240 tiles, one round; N = 2,048 -> 504, two; N = 4,096 -> 1,008, four), and a
+// round costs its tile height (gemm_launch: rounds x height).  The second wave row's code is instantiated on its own (uniform branch
+// per wave: the phase bodies and the epilogue exist once per wave-row height); same chains per output, same bits.
+template <int CONV, int MI1 = 4, int MI1B = MI1>      // CONV 0: plain bf16, 1: implicit-GEMM conv (bf16), 2: plain fp8 (e4m3 x e4m3, scales in the epilogue)
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int total_tiles) {
-    constexpr int MI = 4 + MI1, WR = 16 * MI, TM = 2 * WR;                 // MFMA row tiles per wave, rows per wave row, rows per tile
+    constexpr int MI = 4 + MI1, WR = 16 * MI, TM = WR + 16 * (4 + MI1B);   // MFMA row tiles of a wave of wave row 0 (= the accumulator array's rows), its rows, rows per tile
     static_assert(MI1 == 4 || (MI1 == 3 && CONV != 1), "the conv variant keeps 256-row tiles");
+    static_assert(MI1B <= MI1 && MI1B >= 2, "second wave row: at most as high as the first");
     extern __shared__ __attribute__((aligned(16))) char smem8[];          // the only LDS object: 8 ring slots x 16 KiB + 8 x 4 KiB epilogue staging
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -848,68 +855,79 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
     c.rdA = (unsigned)((wr * 64 + li) * 128 + ((g ^ (li >> 1)) << 4));
     c.rdB = (unsigned)((wc * 32 + li) * 128 + ((g ^ (li >> 1)) << 4));
 
-    f32x4 acc[4][MI];
-    bf16x8 af[4][2], b1[2][2], b0e[2][2], b0o[2][2];
     int n_stamp = 0;
 #define G8_STAMP() do { if (p.stamp && (int)blockIdx.x == p.stamp_wg && tid == 0 && n_stamp < 16) p.stamp[n_stamp++] = wall_clock64(); } while (0)
     G8_STAMP();                                                             // 0: entry (after the address setup)
 
-    // ---- prologue: S[0..6] in flight, S[0] (B0 of tile 0) and S[1] landed before the first reads
-    g8_issue<0, 0, CONV, WR>(c, 0, m0, n0); g8_issue<1, 1, CONV, WR>(c, 0, m0, n0); g8_issue<2, 2, CONV, WR>(c, 0, m0, n0);
-    g8_issue<3, 3, CONV, WR>(c, 0, m0, n0); g8_issue<0, 4, CONV, WR>(c, 1, m0, n0); g8_issue<1, 5, CONV, WR>(c, 1, m0, n0);
-    g8_issue<2, 6, CONV, WR>(c, 1, m0, n0);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    G8_BAR();
-    g8_read_b<0>(c, b0e);
-    G8_STAMP();                                                             // 1: pipeline filled
+    // The whole tile loop of ONE wave-row height (M1 = 16-row tiles in the second half of this wave's rows).  An asymmetric tile
+    // instantiates it twice, each wave running the copy of its row: with one copy branching per phase the register allocator
+    // carried both rows' accumulator live ranges through every phase and spilled 137 dwords (ISA, round 5).  Both copies execute
+    // the same sequence of workgroup barriers.
+    auto tile_loop = [&](auto m1c) {
+        constexpr int M1 = decltype(m1c)::value, MIW = 4 + M1;
+        f32x4 acc[4][MIW];
+        bf16x8 af[4][2], b1[2][2], b0e[2][2], b0o[2][2];
+        // ---- prologue: S[0..6] in flight, S[0] (B0 of tile 0) and S[1] landed before the first reads
+        g8_issue<0, 0, CONV, WR>(c, 0, m0, n0); g8_issue<1, 1, CONV, WR>(c, 0, m0, n0); g8_issue<2, 2, CONV, WR>(c, 0, m0, n0);
+        g8_issue<3, 3, CONV, WR>(c, 0, m0, n0); g8_issue<0, 4, CONV, WR>(c, 1, m0, n0); g8_issue<1, 5, CONV, WR>(c, 1, m0, n0);
+        g8_issue<2, 6, CONV, WR>(c, 1, m0, n0);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        G8_BAR();
+        g8_read_b<0>(c, b0e);
+        G8_STAMP();                                                         // 1: pipeline filled
 
-    const int iters = c.nk >> 1;                                            // two K tiles (8 phases) per trip
-    const int last_it = iters - 1;                                          // the DMA runs 7 half-tiles ahead: the last trip feeds the next tile
-    while (true) {
+        const int iters = c.nk >> 1;                                        // two K tiles (8 phases) per trip
+        const int last_it = iters - 1;                                      // the DMA runs 7 half-tiles ahead: the last trip feeds the next tile
+        while (true) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (wr == 1) G8_BAR();                                             // the second wave row runs one barrier behind
-        for (int it = 0; it < iters; ++it) {
-            const int t2 = 2 * it;
-            const bool seam = CONV != 1 && it == last_it;                  // uniform: issues beyond this tile's K belong to the next tile
-            const int im0 = seam ? m0n : m0, in0 = seam ? n0n : n0;
-            const int wrap = seam ? c.nk : 0;
-            g8_phase<0, CONV, MI1>(c, t2 + 1, m0, n0, acc, af, b1, b0e, b0o);            // S[8it+7]  = A1 of tile 2it+1
-            g8_phase<1, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // S[8it+8]  = B0 of tile 2it+2
-            g8_phase<2, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);
-            g8_phase<3, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // reads B0 of tile 2it+1 into b0o
-            g8_phase<4, CONV, MI1>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // S[8it+11] = A1 of tile 2it+2
-            g8_phase<5, CONV, MI1>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
-            g8_phase<6, CONV, MI1>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
-            g8_phase<7, CONV, MI1>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
-        }
-        if (wr == 0) G8_BAR();                                             // re-align the wave rows
-        G8_STAMP();                                                         // 2 + 2t: K loop of tile t done
-        if constexpr (CONV == 2) {                                          // fp8: per-token and per-weight-row scales (fp32)
-            int lane2 = lane;
-            asm volatile("" : "+v"(lane2));                                // keep these addresses out of the K loop's live ranges
-            const int g2 = lane2 >> 4, li2 = lane2 & 15;
+                for (int i = 0; i < MIW; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (wr == 1) G8_BAR();                                         // the second wave row runs one barrier behind
+            for (int it = 0; it < iters; ++it) {
+                const int t2 = 2 * it;
+                const bool seam = CONV != 1 && it == last_it;              // uniform: issues beyond this tile's K belong to the next tile
+                const int im0 = seam ? m0n : m0, in0 = seam ? n0n : n0;
+                const int wrap = seam ? c.nk : 0;
+                g8_phase<0, CONV, M1, MIW, WR>(c, t2 + 1, m0, n0, acc, af, b1, b0e, b0o);            // S[8it+7]  = A1 of tile 2it+1
+                g8_phase<1, CONV, M1, MIW, WR>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // S[8it+8]  = B0 of tile 2it+2
+                g8_phase<2, CONV, M1, MIW, WR>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);
+                g8_phase<3, CONV, M1, MIW, WR>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0e, b0o);   // reads B0 of tile 2it+1 into b0o
+                g8_phase<4, CONV, M1, MIW, WR>(c, t2 + 2 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // S[8it+11] = A1 of tile 2it+2
+                g8_phase<5, CONV, M1, MIW, WR>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
+                g8_phase<6, CONV, M1, MIW, WR>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);
+                g8_phase<7, CONV, M1, MIW, WR>(c, t2 + 3 - wrap, im0, in0, acc, af, b1, b0o, b0e);   // reads B0 of tile 2it+2 into b0e
+            }
+            if (wr == 0) G8_BAR();                                         // re-align the wave rows
+            G8_STAMP();                                                     // 2 + 2t: K loop of tile t done
+            const int m_wave = m0 + wr * WR;                                // first row of this wave's rows (wave row 1 starts after wave row 0's WR rows)
+            if constexpr (CONV == 2) {                                      // fp8: per-token and per-weight-row scales (fp32)
+                int lane2 = lane;
+                asm volatile("" : "+v"(lane2));                            // keep these addresses out of the K loop's live ranges
+                const int g2 = lane2 >> 4, li2 = lane2 & 15;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nb = min(n0 + wc * 64 + j * 16 + 4 * g2, p.N - 4);
-                const f32x4 sw = *reinterpret_cast<const f32x4*>(p.w_scale + nb);
+                for (int j = 0; j < 4; ++j) {
+                    const int nb = min(n0 + wc * 64 + j * 16 + 4 * g2, p.N - 4);
+                    const f32x4 sw = *reinterpret_cast<const f32x4*>(p.w_scale + nb);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const float sa = p.a_scale[min(m0 + wr * WR + i * 16 + li2, p.M - 1)];
-                    acc[j][i] *= sw * sa;
+                    for (int i = 0; i < MIW; ++i) {
+                        const float sa = p.a_scale[min(m_wave + i * 16 + li2, p.M - 1)];
+                        acc[j][i] *= sw * sa;
+                    }
                 }
             }
+            // all three variants (plain, conv, fp8) carry both the interior and the general path
+            if (p.lds_epi) gemm_epilogue_lds<MIW>(p, acc, m_wave, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
+            else gemm_epilogue<MIW>(p, acc, m_wave, n0 + wc * 64, n0, wc, g, li);
+            G8_STAMP();                                                     // 3 + 2t: epilogue of tile t issued
+            v += gridDim.x;
+            if (CONV == 1 || v >= total_tiles) break;                      // uniform
+            m0 = m0n; n0 = n0n;
+            if (v + (int)gridDim.x < total_tiles) tile_origin(v + gridDim.x, m0n, n0n);
         }
-        if (p.lds_epi) gemm_epilogue_lds<MI, true>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);   // the conv variant has no register to spare for a second path
-        else gemm_epilogue<MI>(p, acc, m0 + wr * WR, n0 + wc * 64, n0, wc, g, li);
-        G8_STAMP();                                                         // 3 + 2t: epilogue of tile t issued
-        v += gridDim.x;
-        if (CONV == 1 || v >= total_tiles) break;                          // uniform
-        m0 = m0n; n0 = n0n;
-        if (v + (int)gridDim.x < total_tiles) tile_origin(v + gridDim.x, m0n, n0n);
-    }
+    };
+    if (MI1B == MI1 || wr == 0) tile_loop(std::integral_constant<int, MI1>{});
+    else tile_loop(std::integral_constant<int, MI1B>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the ring's tail DMAs (clamped re-loads) must land before exit
 }
 
@@ -926,7 +944,7 @@ static int g_gemm_stamp_wg = 0;
 extern "C" int q3asr_gemm_set_stamp_wg(int wg) { g_gemm_stamp_wg = wg; return 0; }     // which workgroup (blockIdx.x) stamps
 
 extern "C" int q3asr_gemm_force_kernel(int mode) {
-    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 8 || mode == 64 || mode == 224, "gemm_force_kernel: mode %d (0 auto, 64, 128, 8 = 8-phase with 256-row tiles, 224 = 8-phase with 224-row tiles)", mode);
+    Q3_REQUIRE(mode == 0 || mode == 128 || mode == 8 || mode == 64 || mode == 224 || mode == 208, "gemm_force_kernel: mode %d (0 auto, 64, 128, 8 = 8-phase with 256-row tiles, 224 / 208 = 8-phase with 224- / 208-row tiles)", mode);
     g_gemm_mode = mode;
     return 0;
 }
@@ -946,7 +964,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
     const bool can8c = conv && p.K >= 256 && (long)p.N * p.ldw < (1L << 31) &&
                        (256L / (p.Hout * p.Wout) + 3) * p.Hin * p.Win * p.Cin * 2 < (1L << 31);
     const bool want8c = can8c && tiles256 >= 192;
-    if (((mode == 8 || mode == 224) && (can8 || can8c)) || (mode == 0 && (want8 || want8c))) {      // deep-pipelined 8-phase kernel
+    if (((mode == 8 || mode == 224 || mode == 208) && (can8 || can8c)) || (mode == 0 && (want8 || want8c))) {      // deep-pipelined 8-phase kernel
         // Tried (round 3, commit 'Experiment: 256x128 half-tile GEMM ...', profiles/r03_gemm2w_experiment.txt): 256 x 128 tiles, 4 waves and
         // an 80 KiB ring so that TWO workgroups share a CU (one's epilogue and pipeline fill under the other's K loop, half-size
         // scheduling units): bit-identical and race-screened, but no faster -- fc1 144.9 vs 143.7 us, encoder qkv 85.9 vs 82.3,
@@ -974,6 +992,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
             attr8 = true;
         }
         if (conv) hipLaunchKernelGGL(gemm8p_kernel<1>, dim3(tiles256), dim3(512), G8_LDS, s, p8, (int)tiles256);
@@ -983,13 +1002,21 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
             // drain before the next tile's counted waits can pass (measured: +8 % at K <= 2048, -2..3 % on long-K or
             // SwiGLU tiles, tools/bench_gemm.py)
             const bool persist = p.K <= 2048 && p.act != 2;
-            // Tile height: a workgroup owns a CU, so a launch costs rounds x tile height; 224-row tiles where that is less
-            // (M = 12,480: 196 tiles of 256 rows or 224 of 224 for N = 1,024 -- one round either way, the second 1/8 shorter).
-            const unsigned tiles224 = (unsigned)((p.M + 223) / 224) * (unsigned)((p.N + G2_T - 1) / G2_T);
-            const bool t224 = mode == 224 || (mode == 0 && ((tiles224 + 255) / 256) * 224u < ((tiles256 + 255) / 256) * 256u);
-            const unsigned tiles8 = t224 ? tiles224 : tiles256;
+            // Tile height: a workgroup owns a CU, so a launch costs about rounds x tile height: 224-row tiles where that is less than with
+            // 256 rows (M = 12,480: 196 tiles of 256 rows or 224 of 224 for N = 1,024 -- one round either way, the second 1/8 shorter),
+            // and 208-row tiles (112 + 96) where that is less again AND the K loop is short: at K = 1,024 (encoder fc1 133.4 / 128.8 / 120.5 us
+            // and qkv 82.9 / 81.1 / 76.0 us at 256 / 224 / 208 rows) the rounds of a launch stay in step and its time follows the tile
+            // height; at K >= 2,048 the 224- and 208-row forms measured within 1 % of each other (prefill qkv 176.8 / 178.0, o 108.1 /
+            // 108.9, down 264.0 / 265.9 us) and the SwiGLU launch is fastest on 256 rows (497 / 534 / 529 us) -- tools/ab_gemm_height.py.
+            const unsigned tn = (unsigned)((p.N + G2_T - 1) / G2_T);
+            const unsigned tiles224 = (unsigned)((p.M + 223) / 224) * tn, tiles208 = (unsigned)((p.M + 207) / 208) * tn;
+            const unsigned c256 = ((tiles256 + 255) / 256) * 256u, c224 = ((tiles224 + 255) / 256) * 224u, c208 = ((tiles208 + 255) / 256) * 208u;
+            const int height = mode == 224 ? 224 : mode == 208 ? 208 : mode == 8 ? 256
+                             : (c224 < c256 ? (p.K <= 1024 && c208 < c224 ? 208 : 224) : 256);
+            const unsigned tiles8 = height == 208 ? tiles208 : (height == 224 ? tiles224 : tiles256);
             const unsigned grid = persist && tiles8 > 256u ? 256u : tiles8;
-            if (t224) hipLaunchKernelGGL((gemm8p_kernel<0, 3>), dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles8);
+            if (height == 208) hipLaunchKernelGGL((gemm8p_kernel<0, 3, 2>), dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles8);
+            else if (height == 224) hipLaunchKernelGGL((gemm8p_kernel<0, 3>), dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles8);
             else hipLaunchKernelGGL(gemm8p_kernel<0>, dim3(grid), dim3(512), G8_LDS, s, p8, (int)tiles8);
         }
         return;
@@ -1096,14 +1123,19 @@ extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale,
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
         (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<2, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
         attr = true;
     }
-    // tile height as in gemm_launch: rounds x height, 224-row tiles where that is less (q3asr_gemm_force_kernel 8 / 224 pin one)
-    const unsigned tiles224 = (unsigned)((M + 223) / 224) * (unsigned)((N + G2_T - 1) / G2_T);
-    const bool t224 = g_gemm_mode == 224 || (g_gemm_mode != 8 && ((tiles224 + 255) / 256) * 224u < ((tiles256 + 255) / 256) * 256u);
-    const unsigned tiles8 = t224 ? tiles224 : tiles256;
+    // tile height as in gemm_launch (q3asr_gemm_force_kernel 8 / 224 / 208 pin one); K counts fp8 elements: 1,024 of them are 8 K tiles
+    const unsigned tn = (unsigned)((N + G2_T - 1) / G2_T);
+    const unsigned tiles224 = (unsigned)((M + 223) / 224) * tn, tiles208 = (unsigned)((M + 207) / 208) * tn;
+    const unsigned c256 = ((tiles256 + 255) / 256) * 256u, c224 = ((tiles224 + 255) / 256) * 224u, c208 = ((tiles208 + 255) / 256) * 208u;
+    const int height = g_gemm_mode == 224 ? 224 : g_gemm_mode == 208 ? 208 : g_gemm_mode == 8 ? 256
+                     : (c224 < c256 ? (K <= 1024 && c208 < c224 ? 208 : 224) : 256);
+    const unsigned tiles8 = height == 208 ? tiles208 : (height == 224 ? tiles224 : tiles256);
     const bool persist = act != 2 && tiles8 > 256u;
-    if (t224) hipLaunchKernelGGL((gemm8p_kernel<2, 3>), dim3(persist ? 256u : tiles8), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles8);
+    if (height == 208) hipLaunchKernelGGL((gemm8p_kernel<2, 3, 2>), dim3(persist ? 256u : tiles8), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles8);
+    else if (height == 224) hipLaunchKernelGGL((gemm8p_kernel<2, 3>), dim3(persist ? 256u : tiles8), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles8);
     else hipLaunchKernelGGL(gemm8p_kernel<2>, dim3(persist ? 256u : tiles8), dim3(512), G8_LDS, (hipStream_t)stream, p, (int)tiles8);
     return q3_check_launch("gemm_fp8");
 }

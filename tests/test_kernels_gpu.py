@@ -217,7 +217,7 @@ def test_gemm_swiglu(dev):
                                    (12480, 1024, 1024),           # the encoder's out projection: 196 tiles of 256 rows, 224 of 224
                                    (70, 128, 64), (130, 192, 192)])   # fewer K tiles than the 64^2 kernel keeps in flight (8-phase n/a: 128^2 twice)
 def test_gemm_kernels_agree_bitwise(dev, M, N, K):
-    """The 64x64, the 128x128 and the 8-phase LDS-DMA kernel (256x256 and 224x256 tiles) accumulate every output in the same order
+    """The 64x64, the 128x128 and the 8-phase LDS-DMA kernel (256x256, 224x256 and 208x256 = 112 + 96 row tiles) accumulate every output in the same order
     (k ascending, one MFMA chain): bit-identical results, plain, fp32-out and through the epilogues (bias+GELU, bf16 residual, SwiGLU),
     including ragged M edges -- which is what makes a clip's result independent of the batch it is decoded in."""
     from qwen3_asr_mlx_amd import _lib, ops
@@ -234,7 +234,7 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     rm = rm.to(dev)
     outs = {}
     try:
-        for mode in (128, 8, 64, 224):
+        for mode in (128, 8, 64, 224, 208):
             _lib.call("q3asr_gemm_force_kernel", mode)
             o32 = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
             ops.gemm(A, W, M, N, K, o32, out_fp32=True)
@@ -252,7 +252,7 @@ def test_gemm_kernels_agree_bitwise(dev, M, N, K):
     finally:
         _lib.call("q3asr_gemm_force_kernel", 0)
     torch.testing.assert_close(outs[8][0].cpu(), _gemm_ref(A, W), atol=2e-3, rtol=1e-3)
-    for mode in (8, 64, 224):
+    for mode in (8, 64, 224, 208):
         for a, b in zip(outs[128], outs[mode]):
             assert torch.equal(a, b), mode
 
@@ -282,7 +282,7 @@ def test_gemm_8phase_direct_epilogue_fallback(dev):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("mode", [8, 224])
+@pytest.mark.parametrize("mode", [8, 224, 208])
 def test_gemm_8phase_is_stable_under_load(dev, mode):
     """Race screen for the 8-phase pipeline (LDS-DMA data is ordered only by counted waits + barriers): 30 back-to-back
     launches of a chip-filling shape, each compared bit for bit with the 128x128 kernel's result; both tile heights."""
@@ -345,7 +345,7 @@ def test_gemm_fp8_on_the_fp8_mfma(dev, M, N, K):
     from qwen3_asr_mlx_amd import _lib
     by_tile = {}
     try:
-        for mode in (8, 224):
+        for mode in (8, 224, 208):
             _lib.call("q3asr_gemm_force_kernel", mode)
             o_a, o_b, o_c = torch.empty_like(out), torch.empty_like(out), torch.empty_like(osw)
             ops.gemm_fp8(a8, sa, q8, sw, M, N, K, o_a)
@@ -354,8 +354,8 @@ def test_gemm_fp8_on_the_fp8_mfma(dev, M, N, K):
             by_tile[mode] = (o_a, o_b, o_c)
     finally:
         _lib.call("q3asr_gemm_force_kernel", 0)
-    for x8, x224, auto in zip(by_tile[8], by_tile[224], (out, out2, osw)):
-        assert torch.equal(x8, x224) and torch.equal(x8, auto)
+    for x8, x224, x208, auto in zip(by_tile[8], by_tile[224], by_tile[208], (out, out2, osw)):
+        assert torch.equal(x8, x224) and torch.equal(x8, x208) and torch.equal(x8, auto)
     # RMSNorm fused quantiser == rmsnorm_bf16 followed by the plain quantiser
     if K in (1024, 2048):
         wn = rnd((K,), dev, 73) + 1

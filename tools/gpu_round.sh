@@ -52,6 +52,7 @@ for step in "$@"; do
     tests_fp8)    run 900 $O/${TAG}_fp8.log python3 -m pytest $R/tests/test_parity_gpu.py -m gpu -q -s -k "fp8_mfma or one_full_size_layer" ; grep -v '^\[parity\]' $O/${TAG}_fp8.log | tail -30 ;;
     bench_gemm)   run 400 $O/${TAG}_bench_gemm.log python3 $R/tools/bench_gemm.py ${BENCH_GEMM_ARGS:-5 8,2} ; cat $O/${TAG}_bench_gemm.log ;;
     longform)     run 500 $O/${TAG}_longform.log python3 $R/tools/longform_variants.py ${LONGFORM_ARGS:-fp8 128} ; grep -v amdgpu.ids $O/${TAG}_longform.log ;;
+    ab_height)    run 500 $O/${TAG}_ab_height.log python3 $R/tools/ab_gemm_height.py ; grep -v amdgpu.ids $O/${TAG}_ab_height.log ;;
     tests_gemm)   run 600 $O/${TAG}_tests_gemm.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k gemm ; tail -8 $O/${TAG}_tests_gemm.log ;;
     admit_cost)   run 300 $O/${TAG}_admit_cost.log python3 $R/tools/admit_cost.py ; grep "k=" $O/${TAG}_admit_cost.log ;;
     attn_stamps)  run 300 $O/${TAG}_attn_stamps.log python3 $R/tools/attn_stamps.py ; grep -v amdgpu.ids $O/${TAG}_attn_stamps.log ;;
