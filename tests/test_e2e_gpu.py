@@ -29,6 +29,7 @@ def small(dev):
 
 def _oracle_parts(cfg, state, gpu_rounding=True):
     import oracle
+    torch.set_num_threads(8)                                # a fixed summation order for the CPU oracle (tests/test_parity_gpu.py, ORACLE_THREADS)
     Wd = {k[len("model."):]: v.float() for k, v in state.items() if k.startswith("model.")}
     We = {k[len("audio_tower."):]: v.float() for k, v in state.items() if k.startswith("audio_tower.")}
     t = cfg.text_decoder
@@ -385,7 +386,7 @@ def test_full_size_5s_clip_greedy_matches_oracle(dev, full):
     import oracle
     import qwen3_asr_mlx_amd as q
     cfg, state, model = full
-    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.set_num_threads(8)
     x = signal("speechlike", 80000)
     cpu_state = {k: v.float().cpu() for k, v in state.items()}
     enc, dec = _oracle_parts(cfg, cpu_state)
