@@ -86,7 +86,10 @@ class KVCache:
             raise ValueError(f"KVCache.update: batch {B} on a cache holding batch {self.batch}")
         layers = max(layer_idx + 1, 0 if self.k is None else self.k.shape[0])
         if self.k is None or B != self.batch or n + T > self.max_len or layers > self.k.shape[0]:
-            dev = key.device if key.is_cuda else (self.k.device if self.k is not None else torch.device(f"cuda:{torch.cuda.current_device()}"))
+            # where the buffers live: the key's device if it is a GPU tensor, else the cache's own, else the current GPU (a host-only process --
+            # the CPU test suite -- keeps them on the host: this method is plain tensor bookkeeping, no kernel runs here)
+            dev = key.device if key.is_cuda else (self.k.device if self.k is not None else
+                                                  (torch.device(f"cuda:{torch.cuda.current_device()}") if torch.cuda.is_available() else key.device))
             self._alloc(layers, B, nkv, hd, max(n + T, 2 * self.max_len if n + T > self.max_len else self.max_len, 64), dev)
         self.k[layer_idx, :, :, n: n + T] = key.to(self.k.device, torch.bfloat16)
         self.v[layer_idx, :, :, n: n + T] = value.to(self.v.device, torch.bfloat16)

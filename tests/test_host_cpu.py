@@ -339,3 +339,40 @@ def test_mlx_conv_layout_maps_to_time_major_taps_at_full_conv_shapes():
         assert float(enc.w["c1_w"][o, kt, kf]) == float(W["conv2d1.weight"][o, kf, kt, 0])
         d, f = int(torch.randint(0, 1024, (1,), generator=g)), int(torch.randint(0, 16, (1,), generator=g))
         assert float(enc.w["co_w"][d, f * C + i]) == float(W["conv_out.weight"][d, i * 16 + f])
+
+
+def test_kv_cache_update_semantics_on_the_host():
+    """KVCache.update (reference decoder.py:32-64, tests/test_decoder.py:254-283) is tensor bookkeeping on pre-allocated buffers: first
+    call of a layer stores, later calls append on axis 2 at the layer's own length, the full accumulated (key, value) comes back as
+    views, `offset` is the caller's, growth in layers and length keeps the contents.  Host tensors here; the GPU suite repeats it on
+    device tensors and through TextDecoder.__call__."""
+    import torch
+    import qwen3_asr_mlx_amd as q
+    g = torch.Generator().manual_seed(3)
+    B, nkv, hd = 2, 8, 128
+    mk = lambda t: torch.randn(B, nkv, t, hd, generator=g).to(torch.bfloat16)      # noqa: E731
+    cache = q.KVCache()
+    assert cache.offset == 0 and cache.keys == [] and cache.values == []
+    k1, v1 = mk(4), mk(4)
+    for layer in range(2):
+        fk, fv = cache.update(layer, k1, v1)
+        assert fk.shape == (B, nkv, 4, hd) and torch.equal(fk, k1) and torch.equal(fv, v1)
+    assert cache.offset == 0 and len(cache.keys) == 2
+    cache.offset = 4
+    k2, v2 = mk(1), mk(1)
+    for layer in range(2):
+        fk, fv = cache.update(layer, k2, v2)
+        assert torch.equal(fk, torch.cat([k1, k2], 2)) and torch.equal(fv, torch.cat([v1, v2], 2))
+    cache.offset = 5
+    k3 = mk(200)                                                            # beyond the first allocation of 64 positions
+    fk, _ = cache.update(0, k3, k3)
+    assert fk.shape == (B, nkv, 205, hd) and torch.equal(fk[:, :, :5], torch.cat([k1, k2], 2)) and torch.equal(fk[:, :, 5:], k3)
+    assert torch.equal(cache.keys[1], torch.cat([k1, k2], 2))               # layer 1 untouched by layer 0's growth
+    fk, _ = cache.update(5, k2, v2)                                          # a deeper layer than the cache has seen: the stack grows
+    assert fk.shape == (B, nkv, 6, hd) and torch.equal(fk[:, :, 5:], k2) and len(cache.keys) == 6
+    with pytest.raises(ValueError):
+        cache.update(0, k2[:, :4], v2[:, :4])
+    with pytest.raises(ValueError):
+        cache.update(0, k2, v2[:, :, :0])
+    with pytest.raises(ValueError):
+        cache.update(0, mk(1)[:1], mk(1)[:1])                               # batch 1 on a cache holding batch 2
