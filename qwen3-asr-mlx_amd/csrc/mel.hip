@@ -241,6 +241,8 @@ extern "C" int q3asr_log_mel_generic(const float* audio, int64_t audio_stride, c
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(gmax_key, 0, sizeof(uint32_t) * B, s) != hipSuccess) return q3_check_launch("log_mel_generic memset");
     const size_t lds = sizeof(double) * n_fft + sizeof(float) * (n_fft / 2 + 1);
+    if (lds > 64 * 1024)                                                 // n_fft > ~6,500: beyond the default dynamic-LDS limit (idempotent call)
+        (void)hipFuncSetAttribute((const void*)mel_logpower_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mel_logpower_generic_kernel, dim3(Fmax, B), dim3(256), lds, s, audio, (long)audio_stride, lens_dev, n_fft,
                        hop_length, n_mels, window, twiddle_cs, fb, out, Fmax, gmax_key);
     hipLaunchKernelGGL(mel_normalize_generic_kernel, dim3((Fmax + 255) / 256, n_mels, B), dim3(256), 0, s, out, lens_dev, gmax_key,
