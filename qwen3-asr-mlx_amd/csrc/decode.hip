@@ -11,6 +11,10 @@
 #include "common.h"
 #include <atomic>
 
+// m-tiles of 16 rows in every X16 image of a step: 1, 2, 3 or 4 (ops.mt_of holds the same rule).  Round 5: three m-tiles for 33-48
+// rows (rounds 1-4 went from 2 straight to 4: the 40 segments of BASELINE configs[4] paid the MFMAs, the X fragments and the
+// partial-sum images of 64 rows).
+static inline int q3_mt_of(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : (M <= 48 ? 3 : 4)); }
 __device__ __forceinline__ long x16_index(int m, int k, int MT) {      // element offset of X[m][k]
     return ((long)(k >> 5) * MT + (m >> 4)) * 512 + ((((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
 }
@@ -296,7 +300,7 @@ static int skinny3_launch(const char* who, const void* X16, const FuseNorm* fuse
     else Q3_REQUIRE(out && n_splits == 1, "%s: direct epilogues need out and n_splits == 1", who);
     if (epi == 1) Q3_REQUIRE(ldo % 4 == 0 && ldo >= N, "%s: bad ldo", who);
     if (epi == 2) Q3_REQUIRE(tiles_per_wave >= 2 && (N / 16) % tiles_per_wave == 0, "%s: SwiGLU needs whole (gate,up) tile pairs per wave", who);
-    const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int MT = q3_mt_of(M);
     const int RT = tiles_per_wave;
     const int n_tiles = N / 16;
     const int per_wg = (wg_ksplit ? 1 : waves_per_wg) * RT;
@@ -318,7 +322,7 @@ static int skinny3_launch(const char* who, const void* X16, const FuseNorm* fuse
 #define Q3_L(MT_, EPI_, RT_, F8_) hipLaunchKernelGGL((skinny3_kernel<MT_, EPI_, RT_, F8_>), grid, blk, lds, s, x, W16, M, N, K, kslice, wg_ksplit, w_scale, slab, o, (long)ldo, fz)
 #define Q3_F(MT_, EPI_, RT_) do { if (w_scale) Q3_L(MT_, EPI_, RT_, true); else Q3_L(MT_, EPI_, RT_, false); } while (0)
 #define Q3_R(MT_, EPI_) do { if (RT == 1) Q3_F(MT_, EPI_, 1); else if (RT == 2) Q3_F(MT_, EPI_, 2); else Q3_F(MT_, EPI_, 4); } while (0)
-#define Q3_M(EPI_) do { if (MT == 1) Q3_R(1, EPI_); else if (MT == 2) Q3_R(2, EPI_); else Q3_R(4, EPI_); } while (0)
+#define Q3_M(EPI_) do { if (MT == 1) Q3_R(1, EPI_); else if (MT == 2) Q3_R(2, EPI_); else if (MT == 3) Q3_R(3, EPI_); else Q3_R(4, EPI_); } while (0)
 #define Q3_LZ(EPI_, RT_, F8_) do {                                                                                                   \
         static std::atomic<bool> attr{false};                                                                                                    \
         if (!attr) { (void)hipFuncSetAttribute((const void*)skinny3_kernel<1, EPI_, RT_, F8_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); attr = true; } \
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(64 * WAVES) void skinny4_kernel(const bf16* __restr
     __shared__ float fred4[4];
     // m-tiles per pass.  The tied head at 17-32 rows takes its two m-tiles one after the other: 113 instead of 137 VGPRs, so two
     // workgroups share a CU and one's loads fly while the other reduces and stores (106.2 -> 101.6 us at 32 rows; same sums).
-    constexpr int MC = (MT < 2 || (EPI == 1 && MT == 2)) ? 1 : 2;
+    // Three m-tiles (33-48 rows): one pass with all three (the weight fragments are converted / consumed once), except for the head.
+    constexpr int MC = (MT < 2 || (EPI == 1 && MT <= 3)) ? 1 : (MT == 3 ? 3 : 2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int bx = blockIdx.x;
     if (EPI == 1 && xcd_map) {
@@ -640,7 +645,7 @@ static int skinny4_launch(const char* who, const void* X16, const FuseNorm* fuse
                    "%s: fused norm needs its own input slabs and distinct h_in / h_out", who);
         Q3_REQUIRE(K % 8 == 0 && (size_t)waves * tiles_per_wg * 1024 + (size_t)K * 8 <= 160 * 1024, "%s: K=%d too large for the fused activation image", who, K);
     }
-    const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int MT = q3_mt_of(M);
     const int xcd_map = epi == 1 && g_q3_option[Q3ASR_OPT_HEAD_XCD_MAP];
     dim3 grid(xcd_map ? (N / 16 / tiles_per_wg + 7) / 8 * 8 : N / 16 / tiles_per_wg, S);   // see the XCD note in the kernel
     hipStream_t s = (hipStream_t)stream;
@@ -668,6 +673,7 @@ static int skinny4_launch(const char* who, const void* X16, const FuseNorm* fuse
     Q3_TRY_F8(1, TPW_, NKS_, EPI_, WAVES_, false)                                       \
     if constexpr ((EPI_) != 1) { Q3_TRY_F8(1, TPW_, NKS_, EPI_, WAVES_, true) }         \
     Q3_TRY_F8(2, TPW_, NKS_, EPI_, WAVES_, false)                                       \
+    if constexpr ((WAVES_) * (TPW_) * 3 <= 160) { Q3_TRY_F8(3, TPW_, NKS_, EPI_, WAVES_, false) } \
     if constexpr ((WAVES_) * (TPW_) * 4 <= 160) { Q3_TRY_F8(4, TPW_, NKS_, EPI_, WAVES_, false) }
     // epilogue 0 (fp32 slabs): the projections; 1 (bf16 rows): the tied head; 2 (SwiGLU -> X16): gate/up
     Q3_TRY_MT(2, 2, 8, 0) Q3_TRY_MT(2, 4, 8, 0) Q3_TRY_MT(2, 6, 8, 0) Q3_TRY_MT(2, 3, 16, 0)
@@ -783,7 +789,7 @@ extern "C" int q3asr_slab_resnorm_x16(const float* slab, int n_slabs, int64_t sl
                                       const void* w, void* x16, int M, int N, float eps, void* stream) {
     Q3_REQUIRE(slab && h_in && h_out && w && x16, "slab_resnorm_x16: null pointer");
     Q3_REQUIRE(M > 0 && M <= 64 && n_slabs > 0 && (N == 512 || N == 1024 || N == 2048 || N == 4096), "slab_resnorm_x16: M=%d N=%d unsupported", M, N);
-    const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int MT = q3_mt_of(M);
     dim3 grid(M), blk(256);
     hipStream_t s = (hipStream_t)stream;
     const bf16* hi = (const bf16*)h_in; bf16* ho = (bf16*)h_out; const bf16* ww = (const bf16*)w; bf16* xo = (bf16*)x16;
@@ -850,7 +856,7 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, vo
     Q3_REQUIRE(E && h_out && w && x16, "embed_norm_x16: null pointer");
     Q3_REQUIRE(M > 0 && M <= 64 && (N == 512 || N == 1024 || N == 2048 || N == 4096), "embed_norm_x16: M=%d N=%d unsupported", M, N);
     Q3_REQUIRE(V > 0 && (tok || V >= M), "embed_norm_x16: E has V=%d rows (M=%d rows are read when tok is NULL)", V, M);
-    const int MT = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int MT = q3_mt_of(M);
     dim3 grid(M), blk(256);
     hipStream_t s = (hipStream_t)stream;
     const bf16* e = (const bf16*)E; bf16* ho = (bf16*)h_out; const bf16* ww = (const bf16*)w; bf16* xo = (bf16*)x16;
@@ -1208,7 +1214,7 @@ extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_
     Q3_REQUIRE(qkv_slab && n_slabs > 0 && qn_w && kn_w && inv_freq && k_cache && v_cache && pos && out && workspace, "attn_decode_fused: null pointer");
     Q3_REQUIRE(head_dim == 128 && nh == 2 * nkv, "attn_decode_fused: needs head_dim 128 and 2 query heads per kv head");
     Q3_REQUIRE(B > 0 && B <= 64 && Lmax > 0 && ld >= (int64_t)(nh + 2 * nkv) * 128, "attn_decode_fused: bad sizes");
-    const int MT = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+    const int MT = q3_mt_of(B);
     const int nc = (Lmax + ADF_CHUNK - 1) / ADF_CHUNK;
     Q3_REQUIRE(nc <= 65535, "attn_decode_fused: Lmax=%d too long", Lmax);
     float* part = (float*)workspace;

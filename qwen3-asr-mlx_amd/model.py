@@ -48,16 +48,23 @@ def _find_split_points(samples: np.ndarray, chunk_samples: int, search_samples: 
     if n_frames == 0:
         return []
     frames = np.asarray(samples[: n_frames * frame_samples], dtype=np.float32).reshape(n_frames, frame_samples)
-    energy = np.sqrt(np.mean(frames ** 2, axis=1)).astype(np.float32)
     radius = search_samples // frame_samples
+    boundaries = range(chunk_samples, total, chunk_samples)
+    # The reference takes the RMS of every frame and then looks at 2 * radius + 1 of them per boundary.  A frame's energy is a
+    # row-wise reduction (independent of the other rows), so the search windows alone give the same float32 values: a third of
+    # the samples at 30 s chunks (12 -> 4 ms of host time per 20 min of audio).  Overlapping windows (chunks shorter than the
+    # search span) fall back to one pass over everything.
+    windowed = len(boundaries) * (2 * radius + 1) < n_frames
+    energy = None if windowed else np.sqrt(np.mean(frames ** 2, axis=1)).astype(np.float32)
     points: list[int] = []
-    for boundary in range(chunk_samples, total, chunk_samples):
+    for boundary in boundaries:
         centre = boundary // frame_samples
         lo, hi = max(0, centre - radius), min(n_frames - 1, centre + radius)
         if lo >= hi:
             points.append(boundary)
         else:
-            points.append((int(np.argmin(energy[lo: hi + 1])) + lo) * frame_samples)
+            e = np.sqrt(np.mean(frames[lo: hi + 1] ** 2, axis=1)) if windowed else energy[lo: hi + 1]
+            points.append((int(np.argmin(e)) + lo) * frame_samples)
     return points
 
 

@@ -72,7 +72,7 @@ def attn_fwd(Q, q_stride, K, V, kv_seg_off, kv_head_stride, kv_row_stride, O, o_
 
 # ---------------------------------------------------------------- decode-step streaming layouts
 def mt_of(M: int) -> int:
-    return 1 if M <= 16 else (2 if M <= 32 else 4)
+    return 1 if M <= 16 else (2 if M <= 32 else (3 if M <= 48 else 4))
 
 
 def to_w16(W):
@@ -191,7 +191,7 @@ def gemm_geometry4(N: int, K: int, epi: int, fp8: bool = False, M: int = 32):
         g = (2, 2, 8)
         if not fits(g):
             return None
-    if M > 32 and g[2] * g[0] * 4 > 160:              # partial sums of 4 m-tiles must fit LDS: halve the tiles
+    if M > 32 and g[2] * g[0] * mt_of(M) > 160:       # partial sums of 3 / 4 m-tiles must fit LDS: halve the tiles
         g = (g[0] // 2, g[1], g[2])
         if not fits(g):
             return None

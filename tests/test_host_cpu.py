@@ -73,6 +73,12 @@ def test_filterbank_and_prompt_and_splitter_match_fixtures():
     got = f(long, 30 * sr, 5 * sr)
     assert got == sp["rng3_20min_30s"] and len(got) == 39 and got[:3] == [485280, 928800, 1394400]
     assert f(np.ones(100, np.float32), 50, 10) == []
+    # the windowed energy computation (search windows only) and the all-frames form are the same float32 values: both branches
+    # against a restatement that always takes every frame's RMS, windows that do and do not overlap, ragged tail
+    import oracle
+    x = (np.random.default_rng(7).standard_normal(sr * 130 + 123) * 0.1).astype(np.float32)
+    for chunk, search in ((30 * sr, 5 * sr), (8 * sr, 5 * sr), (3 * sr, 2 * sr), (20 * sr, sr // 2), (sr, sr)):
+        assert f(x, chunk, search) == oracle.find_split_points(x, chunk, search), (chunk, search)
 
 
 def test_config_parsing():
@@ -203,6 +209,9 @@ def test_decode_split_choice():
             g64 = ops.gemm_geometry4(n, k, epi, fp8, 64)
             assert g64[1:] == g[1:] and g64[2] * g64[0] * 4 <= 160
             assert ops.gemm_geometry4(n, k, epi, fp8, 1) == g
+            g40 = ops.gemm_geometry4(n, k, epi, fp8, 40)            # 33-48 rows: three m-tiles of partial sums
+            assert g40[1:] == g[1:] and g40[2] * g40[0] * 3 <= 160
+    assert [ops.mt_of(m) for m in (1, 16, 17, 32, 33, 40, 48, 49, 64)] == [1, 1, 2, 2, 3, 3, 3, 4, 4]
     assert ops.gemm_geometry4(1024, 512, 0) == (2, 2, 8) and ops.gemm_geometry4(2048, 512, 2) == (2, 2, 8)
     assert ops.gemm_geometry4(151936, 512, 1) == (2, 2, 8) and ops.gemm_geometry4(512, 1024, 0) == (2, 2, 8)
     assert ops.gemm_geometry4(1024, 256, 0) is None and ops.gemm_geometry4(48, 512, 0) is None

@@ -916,8 +916,8 @@ def _sk4_run(ops, dev, x16, M, wt, scale, N, K, epi, geo):
 @pytest.mark.parametrize("N,K,epi,geo", SK4_CASES)
 def test_skinny4_matches_reference_and_is_batch_invariant(dev, N, K, epi, geo, fp8):
     """q3asr_skinny4_gemm against an fp32 product for every instantiated geometry and epilogue, bf16 and fp8 weights, at
-    M = 1 .. 64 (all three m-tile counts, ragged last tile); and the rows of a 64-row launch equal, bit for bit, the same
-    rows computed alone or in a 20-row launch (the k partition depends on the geometry only)."""
+    M = 1 .. 64 (all four m-tile counts -- 1, 2, 3 for 33-48 rows, 4 -- ragged last tile); and the rows of the largest launch
+    equal, bit for bit, the same rows computed alone or in any smaller launch (the k partition depends on the geometry only)."""
     from qwen3_asr_mlx_amd import ops
     tpw, nks, waves = geo
     if fp8 and nks % 2:
@@ -931,9 +931,9 @@ def test_skinny4_matches_reference_and_is_batch_invariant(dev, N, K, epi, geo, f
         scale, w_eff, wt = None, W, ops.to_w16(W)
     ref_all = X.float().cpu() @ w_eff.float().cpu().T
     results = {}
-    for M in (64, 33, 32, 20, 16, 7, 1):
-        if M > 32 and waves * tpw * 4 > 160:
-            continue                                      # 4 m-tiles of partial sums do not fit LDS: the decoder halves the tiles
+    for M in (64, 48, 40, 33, 32, 20, 16, 7, 1):
+        if M > 32 and waves * tpw * ops.mt_of(M) > 160:
+            continue                                      # 3 / 4 m-tiles of partial sums do not fit LDS: the decoder halves the tiles
         got = _sk4_run(ops, dev, ops.to_x16(X[:M].contiguous()), M, wt, scale, N, K, epi, geo)
         ref = ref_all[:M]
         if epi == 0:
