@@ -24,6 +24,7 @@ extern int g_q3_option[8];
 #define Q3ASR_OPT_HEAD_XCD_MAP 1      // the ids of include/q3asr.h
 #define Q3ASR_OPT_HEAD_STREAM 2
 #define Q3ASR_OPT_ATTN_XCD_ORDER 3
+#define Q3ASR_OPT_SAMPLER_RESIDENT 4
 int q3_check_launch(const char* what);
 
 #define Q3_REQUIRE(cond, ...)                 \

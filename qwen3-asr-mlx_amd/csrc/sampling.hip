@@ -23,6 +23,11 @@
 //       Filter maths in fp32 (the reference's bf16 cumsum saturation is not reproduced:
 //       distributional parity only).
 //   bookkeeping         append to out_tokens unless finished, EOS / budget -> finished, advance pos.
+// Round 5: rows of up to 155,648 logits (the 151,936 of Qwen3-ASR) stay ON CHIP across the passes: thread t owns the 16-byte
+// chunks t, t + 1024, ... (19 of them), all requested before the first is consumed (one memory round trip instead of five
+// groups of four loads in flight), and held after the penalty and the temperature have been applied once -- 16 chunks in
+// registers (64 of the 128 VGPRs a 1024-thread workgroup may use), 3 in LDS -- so the window and locate passes read no memory.
+// Longer rows stream as before (q3asr_set_option(Q3ASR_OPT_SAMPLER_RESIDENT, 0) forces that form: same tokens).
 #include "common.h"
 #include <atomic>
 
@@ -34,6 +39,9 @@
 #define SMP_WIN_KEYS (SMP_WIN_BINS * 16)
 #define SMP_CNT_SHIFT 44              // hist word = count << 44 | sum of round(2^24 * exp(v - top(bin)))
 #define SMP_MASS_ONE 16777216.0f
+#define SMP_RES 19                    // resident 16-byte chunks per thread ...
+#define SMP_RES_LDS_BYTES ((SMP_RES - 16) * 16 * SMP_THREADS)
+#define SMP_RES_REG 16                // ... of which in registers across the passes; the other 3 sit in LDS (48 KiB), see resident_pass
 
 struct SampleParams {
     const bf16* logits; long ld; int V;
@@ -121,27 +129,93 @@ __device__ __forceinline__ void decode8(const bf16x8 raw, unsigned bits, int c, 
     }
 }
 
-// One coalesced pass over the row, 4 x 16-byte loads in flight per thread; f(chunk, values[8]).
+// One coalesced pass over the row, 4 x 16-byte loads in flight per thread.  Thread t sees the chunks t + 1024 j in ascending j;
+// f(j, chunk, values[8], valid) is called by EVERY thread for every j < ceil(nchunks / 1024) (wave-uniform control flow: f may
+// reduce across the wave); `valid` is false past the end of the row, where the values are those of the last chunk.
 template <typename F>
 __device__ __forceinline__ void stream_row(const bf16* row, int nchunks, const unsigned char* bitmap, const SmpShared& sh,
                                            bool scaled, float t_bf, F&& f) {
-    for (int c0 = threadIdx.x; c0 < nchunks; c0 += 4 * SMP_THREADS) {
+    const int iters = (nchunks + SMP_THREADS - 1) / SMP_THREADS;
+    for (int j0 = 0; j0 < iters; j0 += 4) {
         bf16x8 raw[4];
         unsigned bits[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int c = min(c0 + u * SMP_THREADS, nchunks - 1);
+            const int c = min((j0 + u) * SMP_THREADS + (int)threadIdx.x, nchunks - 1);
             raw[u] = *reinterpret_cast<const bf16x8*>(row + 8 * c);
             bits[u] = bitmap[c];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int c = c0 + u * SMP_THREADS;
-            if (c >= nchunks) break;
+            if (j0 + u >= iters) break;
+            const int c = (j0 + u) * SMP_THREADS + (int)threadIdx.x;
             float v[8];
-            decode8(raw[u], bits[u], c, sh, scaled, t_bf, v);
-            f(c, v);
+            decode8(raw[u], bits[u], min(c, nchunks - 1), sh, scaled, t_bf, v);
+            f(j0 + u, c, v, c < nchunks);
         }
+    }
+}
+
+// The resident form.  The row lives in 19 x 4 registers per thread as raw 32-bit words (two bf16 each).
+typedef unsigned smp_u32x4 __attribute__((ext_vector_type(4)));
+// request the thread's SMP_RES chunks (all in flight at once) ...
+__device__ __forceinline__ void resident_load(const bf16* row, int nchunks, smp_u32x4 (&rr)[SMP_RES]) {
+#pragma unroll
+    for (int j = 0; j < SMP_RES; ++j) {
+        const int c = min(j * SMP_THREADS + (int)threadIdx.x, nchunks - 1);
+        rr[j] = *reinterpret_cast<const smp_u32x4*>(row + 8 * c);
+    }
+}
+__device__ __forceinline__ void unpack8(const smp_u32x4 w, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+}
+// ... first pass: apply the penalty and the temperature once, keep the results and hand them to f ...
+template <typename F>
+__device__ __forceinline__ void resident_first_pass(int nchunks, const unsigned char* bitmap, const SmpShared& sh, bool scaled, float t_bf,
+                                                    smp_u32x4 (&rr)[SMP_RES], smp_u32x4* lrow, F&& f) {
+    const int iters = (nchunks + SMP_THREADS - 1) / SMP_THREADS;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));                                       // the 19 clamped chunk indices of resident_load are not kept alive for this loop
+#pragma unroll
+    for (int j = 0; j < SMP_RES; ++j) {
+        if (j < iters) {                                                 // uniform; no break: the loop must unroll (static register indices)
+            const int c = j * SMP_THREADS + tid_, cc = min(c, nchunks - 1);
+            float v[8];
+            decode8(__builtin_bit_cast(bf16x8, rr[j]), bitmap[cc], cc, sh, scaled, t_bf, v);
+            smp_u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)                                  // exact: v holds bf16 values
+                w[i] = (__float_as_uint(v[2 * i]) >> 16) | (__float_as_uint(v[2 * i + 1]) & 0xFFFF0000u);
+            if (j < SMP_RES_REG) rr[j] = w;
+            else lrow[(j - SMP_RES_REG) * SMP_THREADS + tid_] = w;       // the thread's own slot: no barrier between its write and its reads
+            f(j, c, v, c < nchunks);
+        }
+        __builtin_amdgcn_sched_barrier(0);                               // one chunk's temporaries at a time
+    }
+}
+// ... and every later pass is a walk over registers (chunks 0-15) and LDS (16-18: the phase logic between the passes keeps ~60
+// registers alive, and 76 + 60 > 128), with stream_row's calling convention.  The empty asm makes a chunk's registers opaque
+// at each use: the passes run inside the phase loop, where hipcc otherwise hoists the 152 unpacked values (and their keys) of the
+// loop-invariant row out of the loop and spills them (3 KiB of scratch per lane).
+template <typename F>
+__device__ __forceinline__ void resident_pass(int nchunks, smp_u32x4 (&rr)[SMP_RES], const smp_u32x4* lrow, F&& f) {
+    const int iters = (nchunks + SMP_THREADS - 1) / SMP_THREADS;
+#pragma unroll
+    for (int j = 0; j < SMP_RES; ++j) {
+        if (j < iters) {
+            const int c = j * SMP_THREADS + (int)threadIdx.x;
+            smp_u32x4 w;
+            if (j < SMP_RES_REG) { asm volatile("" : "+v"(rr[j])); w = rr[j]; }
+            else w = lrow[(j - SMP_RES_REG) * SMP_THREADS + threadIdx.x];
+            float v[8];
+            unpack8(w, v);
+            f(j, c, v, c < nchunks);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -192,6 +266,8 @@ __device__ __forceinline__ void commit_token(const SampleParams& p, int b, int n
 }
 
 // ------------------------------------------------------------------------------------------- greedy
+// (The resident form of the draw kernel below does not pay here: one pass, nothing to re-read, and 88 instead of 40 VGPRs --
+// 15.8 vs 14.8 us per launch at 40 rows, tools/ab_sampler.py.)
 __global__ __launch_bounds__(SMP_THREADS) void sample_greedy_kernel(const SampleParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ SmpShared sh;
@@ -204,7 +280,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_greedy_kernel(const Sample
 
     float best = -INFINITY;
     int best_i = 0x7fffffff;
-    stream_row(row, nchunks, bitmap, sh, false, 1.0f, [&](int c, const float (&v)[8]) {
+    stream_row(row, nchunks, bitmap, sh, false, 1.0f, [&](int, int c, const float (&v)[8], bool valid) {
+        if (!valid) return;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             if (v[e] > best) { best = v[e]; best_i = 8 * c + e; }
@@ -305,25 +382,35 @@ __device__ __forceinline__ float mass_before(const float (&m)[4], float pre, int
     return e;
 }
 
+template <bool RES>
 __global__ __launch_bounds__(SMP_THREADS) void sample_draw_kernel(const SampleParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ SmpShared sh;
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(dyn);               // [4096]
     unsigned* fine = reinterpret_cast<unsigned*>(dyn + SMP_BINS * 8);                    // [2][2048]
-    unsigned char* bitmap = dyn + SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4;                   // V/8 bytes
+    smp_u32x4* lrow = reinterpret_cast<smp_u32x4*>(dyn + SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4);    // RES: [3][1024] chunks
+    unsigned char* bitmap = dyn + SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4 + (RES ? SMP_RES_LDS_BYTES : 0);   // V/8 bytes
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bf16* row = p.logits + (long)b * p.ld;
     const int nchunks = p.V / 8;
     const int n = p.n_gen[b];
     const float t_bf = round_bf(p.temperature);
     SMP_T(0);
+    smp_u32x4 rr[SMP_RES];
+    if constexpr (RES) resident_load(row, nchunks, rr);                 // in flight during the penalty set-up
     penalty_setup(p, row, b, n, bitmap, sh);
+    // one pass over the row's (penalised, scaled) values: registers (after the first pass has put them there) or a streaming re-read
+    auto each = [&](auto&& f) {
+        if constexpr (RES) resident_pass(nchunks, rr, lrow, f);
+        else stream_row(row, nchunks, bitmap, sh, true, t_bf, f);
+    };
     SMP_T(1);
 
     // ---- pass 1: 4096-bin histogram (count + mass relative to each bin's largest value)
     for (int i = tid; i < SMP_BINS; i += SMP_THREADS) hist[i] = 0ull;
     __syncthreads();
-    stream_row(row, nchunks, bitmap, sh, true, t_bf, [&](int, const float (&v)[8]) {
+    auto to_hist = [&](int, int, const float (&v)[8], bool valid) {
+        if (!valid) return;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const unsigned k = key16(v[e]);
@@ -331,7 +418,9 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_draw_kernel(const SamplePa
             const float rel = v[e] == top ? 1.0f : __expf(v[e] - top);                   // (-inf) - (-inf) stays out of exp
             atomicAdd(&hist[k >> 4], (1ull << SMP_CNT_SHIFT) | (unsigned long long)(unsigned)(rel * SMP_MASS_ONE + 0.5f));
         }
-    });
+    };
+    if constexpr (RES) resident_first_pass(nchunks, bitmap, sh, true, t_bf, rr, lrow, to_hist);
+    else stream_row(row, nchunks, bitmap, sh, true, t_bf, to_hist);
     __syncthreads();
 
     SMP_T(2);
@@ -405,7 +494,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_draw_kernel(const SamplePa
             for (int i = tid; i < 2 * SMP_WIN_KEYS; i += SMP_THREADS) fine[i] = 0u;
             __syncthreads();
             const unsigned baseA = (unsigned)wbA << 4, baseB = wbB >= 0 ? (unsigned)wbB << 4 : 0x10000u;
-            stream_row(row, nchunks, bitmap, sh, true, t_bf, [&](int, const float (&v)[8]) {
+            each([&](int, int, const float (&v)[8], bool valid) {
+                if (!valid) return;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const unsigned k = key16(v[e]);
@@ -500,35 +590,19 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_draw_kernel(const SamplePa
     SMP_T(16);
     int token = 0;
     {
-        // ---- the r-th logit (index order) whose key is key_d.  Wave w owns chunks [w*per_w, (w+1)*per_w),
-        // iteration i covers 64 consecutive chunks: index order = (wave, iteration, lane, element).
-        const int iters = (nchunks + SMP_THREADS - 1) / SMP_THREADS;     // <= 64 (host check), so wave*iters+i < 1024
-        const int per_w = iters * 64;
-        for (int i0 = 0; i0 < iters; i0 += 4) {                          // 4 x 16-byte loads in flight per lane
-            bf16x8 raw[4];
-            unsigned bits[4];
+        // ---- the r-th logit (index order) whose key is key_d.  Pass j covers the 1024 consecutive chunks 1024 j + tid, a wave 64
+        // of them: index order = (pass, wave, lane, element), one segment count per (pass, wave).
+        const int iters = (nchunks + SMP_THREADS - 1) / SMP_THREADS;     // <= 64 (host check), so iters * SMP_WAVES <= 1024
+        each([&](int j, int, const float (&v)[8], bool valid) {
+            int hits = 0;
+            if (valid) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = min(wv * per_w + (i0 + u) * 64 + lane, nchunks - 1);
-                raw[u] = *reinterpret_cast<const bf16x8*>(row + 8 * c);
-                bits[u] = bitmap[c];
+                for (int e = 0; e < 8; ++e) hits += (key16(v[e]) == key_d);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (i0 + u >= iters) break;
-                const int c = wv * per_w + (i0 + u) * 64 + lane;
-                int hits = 0;
-                if (c < nchunks) {
-                    float v[8];
-                    decode8(raw[u], bits[u], c, sh, true, t_bf, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) hits += (key16(v[e]) == key_d);
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o, 64);
-                if (lane == 0) sh.scratch[wv * iters + i0 + u] = hits;
-            }
-        }
+            for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o, 64);
+            if (lane == 0) sh.scratch[j * SMP_WAVES + wv] = hits;
+        });
         __syncthreads();
         SMP_T(17);
         const int seg_hits = tid < SMP_WAVES * iters ? sh.scratch[tid] : 0;
@@ -539,8 +613,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_draw_kernel(const SamplePa
         if (seg_hits > 0 && seg_before <= r && r < seg_before + seg_hits) { sh.bc_i[2] = tid; sh.bc_i[3] = r - seg_before; }
         __syncthreads();
         const int seg = sh.bc_i[2];
-        if (seg >= 0 && wv == seg / iters) {
-            const int c = wv * per_w + (seg % iters) * 64 + lane;
+        if (seg >= 0 && wv == seg % SMP_WAVES) {                         // one 1 KiB re-read by the owning wave (a register of a
+            const int c = (seg / SMP_WAVES) * SMP_THREADS + tid;         // run-time index would live in scratch memory)
             float v[8];
             int hits = 0;
             if (c < nchunks) {
@@ -577,17 +651,21 @@ extern "C" int q3asr_sample_step(const void* logits, int64_t ld, int B, int V, i
     p.temperature = temperature; p.top_p = top_p; p.penalty = penalty; p.top_k = top_k; p.ctx = ctx; p.seed = seed;
     p.eos0 = eos0; p.eos1 = eos1; p.row_base = row_base;
     const size_t bitmap = (size_t)((V / 8 + 15) / 16) * 16;
+    const bool res = V <= SMP_RES * 8 * SMP_THREADS && g_q3_option[Q3ASR_OPT_SAMPLER_RESIDENT];
     if (temperature == 0.0f) {
         hipLaunchKernelGGL(sample_greedy_kernel, dim3(B), dim3(SMP_THREADS), bitmap, (hipStream_t)stream, p);
     } else {
-        const size_t lds = SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4 + bitmap; // up to 112 KiB: needs the opt-in (once per process)
+        const size_t lds = SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4 + bitmap + (res ? SMP_RES_LDS_BYTES : 0);   // up to 116 KiB: needs the opt-in (once per process)
         static std::atomic<bool> attr_set{false};
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)sample_draw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute((const void*)sample_draw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4 + SMP_RES_LDS_BYTES + SMP_RES * SMP_THREADS);
+            (void)hipFuncSetAttribute((const void*)sample_draw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       SMP_BINS * 8 + 2 * SMP_WIN_KEYS * 4 + 64 * SMP_THREADS);
             attr_set = true;
         }
-        hipLaunchKernelGGL(sample_draw_kernel, dim3(B), dim3(SMP_THREADS), lds, (hipStream_t)stream, p);
+        if (res) hipLaunchKernelGGL(sample_draw_kernel<true>, dim3(B), dim3(SMP_THREADS), lds, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(sample_draw_kernel<false>, dim3(B), dim3(SMP_THREADS), lds, (hipStream_t)stream, p);
     }
     return q3_check_launch("sample_step");
 }

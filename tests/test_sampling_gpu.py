@@ -264,3 +264,47 @@ def test_sampling_is_reproducible_for_a_seed(dev):
     a = _draw_many(row, 256, 0.8, top_p=0.9, top_k=100)
     b = _draw_many(row, 256, 0.8, top_p=0.9, top_k=100)
     assert (a == b).all() and len(set(a.tolist())) > 1
+
+
+def _step_with_penalty(dev, logits, temperature, top_p, top_k, seed, history):
+    """One q3asr_sample_step over a batch whose rows already generated `history` (the penalty window)."""
+    from qwen3_asr_mlx_amd import ops
+    B, V = logits.shape
+    n = len(history[0])
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)      # noqa: E731
+    out_tokens = i32([list(h) + [0] for h in history])
+    n_gen, fin, cur, pos, mx = i32([n] * B), i32([0] * B), i32([0] * B), i32([0] * B), i32([n + 1] * B)
+    ops.call("q3asr_sample_step", ops.ptr(logits), V, B, V, ops.ptr(out_tokens), n + 1, ops.ptr(n_gen), ops.ptr(fin),
+             ops.ptr(cur), ops.ptr(pos), ops.ptr(mx), float(temperature), float(top_p), int(top_k), 1.2, 100, seed, -1, -1, 0, ops.sp())
+    return cur.tolist()
+
+
+@pytest.mark.parametrize("V", [151936, 4096, 1056, 155648, 155680, 200000])
+def test_resident_and_streaming_sampler_forms_pick_the_same_tokens(dev, V):
+    """Rows of <= 155,648 logits are held in registers / LDS across the sampler's passes, longer rows are re-read by every
+    pass; q3asr_set_option(Q3ASR_OPT_SAMPLER_RESIDENT, 0) forces the streaming form.  Same tokens from both, greedy and
+    drawn, with a repetition penalty in force, for vocabularies that end inside a pass, at the capacity, and beyond it
+    (where both settings stream)."""
+    from qwen3_asr_mlx_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(V)
+    B = 24
+    logits = (torch.randn(B, V, generator=g) * 2.5).to(torch.bfloat16).to(dev)
+    history = [[int(t) for t in torch.randint(0, V, (20,), generator=g)] for _ in range(B)]
+    for b in range(B):                                   # the penalty must matter: the row's best logits are in the window
+        history[b][:3] = [int(i) for i in torch.topk(logits[b].float(), 3).indices]
+    got = {}
+    try:
+        for res in (1, 0):
+            lib.q3asr_set_option(4, res)
+            got[res] = [_step_with_penalty(dev, logits, *cfg, history) for cfg in
+                        ((0.0, 1.0, 0, 1), (0.7, 0.9, 0, 2), (1.0, 1.0, 50, 3), (0.8, 0.95, 200, 4), (1.3, 1.0, 0, 5))]
+    finally:
+        lib.q3asr_set_option(4, 1)
+    assert got[1] == got[0]
+    greedy = got[1][0]
+    for b in range(B):                                   # and the greedy pick is the penalised argmax (oracle arithmetic)
+        import oracle
+        ref = oracle.apply_repetition_penalty(logits[b].float().cpu(), history[b], 1.2)
+        assert greedy[b] == int(torch.argmax(ref))
+    assert len(set(got[1][1])) > 1

@@ -56,6 +56,7 @@ for step in "$@"; do
     tests_gemm)   run 600 $O/${TAG}_tests_gemm.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k gemm ; tail -8 $O/${TAG}_tests_gemm.log ;;
     admit_cost)   run 300 $O/${TAG}_admit_cost.log python3 $R/tools/admit_cost.py ; grep "k=" $O/${TAG}_admit_cost.log ;;
     attn_stamps)  run 300 $O/${TAG}_attn_stamps.log python3 $R/tools/attn_stamps.py ; grep -v amdgpu.ids $O/${TAG}_attn_stamps.log ;;
+    ab_sampler)   run 300 $O/${TAG}_ab_sampler.log python3 $R/tools/ab_sampler.py ${AB_SAMPLER_ARGS:-40 5 40} ; grep -v amdgpu.ids $O/${TAG}_ab_sampler.log ;;
     ab_attn)      run 300 $O/${TAG}_ab_attn.log python3 $R/tools/ab_attn.py ${AB_ATTN_ARGS:-3} ; grep -v amdgpu.ids $O/${TAG}_ab_attn.log ;;
     tests_attn)   run 600 $O/${TAG}_tests_attn.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k attn ; tail -5 $O/${TAG}_tests_attn.log ;;
     serve)        run 500 $O/${TAG}_serve32.log python3 $R/tools/bench_serve.py 32 25,60,90,120 6 ; tail -1 $O/${TAG}_serve32.log > $O/${TAG}_serve32.json; grep offered $O/${TAG}_serve32.log | cut -c1-200
