@@ -201,6 +201,8 @@ __device__ __forceinline__ void resident_first_pass(int nchunks, const unsigned 
 // registers alive, and 76 + 60 > 128), with stream_row's calling convention.  The empty asm makes a chunk's registers opaque
 // at each use: the passes run inside the phase loop, where hipcc otherwise hoists the 152 unpacked values (and their keys) of the
 // loop-invariant row out of the loop and spills them (3 KiB of scratch per lane).
+// (What remains in scratch: 18 loop-invariant dwords of the phase logic -- shuffle addresses, 1 / temperature, wave id -- stored once
+// and re-read between the passes, none of them inside a pass.)
 template <typename F>
 __device__ __forceinline__ void resident_pass(int nchunks, smp_u32x4 (&rr)[SMP_RES], const smp_u32x4* lrow, F&& f) {
     const int iters = (nchunks + SMP_THREADS - 1) / SMP_THREADS;
