@@ -464,9 +464,12 @@ def main() -> None:
         e2e = {"single": [], "grouped": []}
         h2d = {}
         res_ = None
-        for i in range(5):
-            for mode in sorted(e2e, key=lambda m_: m_ == default_mode):      # the default runs second in each pair
-                qaudio.PACK_MODE = mode
+        # One block per form, the shipped default last; two untimed runs open a block.  (Round 5 alternated the forms run by run: on
+        # some boxes the first runs after a change of form carry a 5-35 ms host-fill spike -- tools/e2e_probe.py prints every run --
+        # and with strict alternation every run is such a first run.)  `runs_ms` keeps every timed run, so a spike shows as one.
+        for mode in sorted(e2e, key=lambda m_: m_ == default_mode):
+            qaudio.PACK_MODE = mode
+            for i in range(7):
                 st_ = qaudio.PACK_STATS = {}
                 torch.cuda.synchronize()
                 s0 = time.perf_counter()
@@ -474,7 +477,7 @@ def main() -> None:
                 torch.cuda.synchronize()
                 dt_ = time.perf_counter() - s0
                 qaudio.PACK_STATS = None
-                if i:
+                if i >= 2:
                     e2e[mode].append(dt_)
                     h2d.setdefault(mode, []).append(qaudio.pack_stats_finish(st_))
         qaudio.PACK_MODE = default_mode
@@ -487,7 +490,8 @@ def main() -> None:
             return {"mode": mode, "bytes": recs[0]["bytes"], "groups": recs[0]["groups"], "pinned": recs[0]["pinned"],
                     "setup_ms": f_("setup_ms"), "host_fill_ms": f_("host_fill_ms"), "copy_issue_ms": f_("copy_issue_ms"),
                     "copy_span_ms": f_("copy_span_ms"), "copy_GBps_over_span": recs[0]["bytes"] / (f_("copy_span_ms") * 1e-3) / 1e9,
-                    "host_total_ms": f_("host_total_ms"), "p50_latency_ms": 1e3 * med[mode]}
+                    "host_total_ms": f_("host_total_ms"), "p50_latency_ms": 1e3 * med[mode],
+                    "runs_ms": [round(1e3 * v_, 1) for v_ in e2e[mode]]}
         line["end_to_end"] = {"value": B * args.clip_seconds / med[default_mode], "unit": "audio-s/wall-s",
                               "p50_latency_ms": 1e3 * med[default_mode], "conforms_to": "SURVEY.md 8d (H2D of the audio inside the timed region)",
                               "note": "Qwen3ASR.transcribe_batch(list of host float32 arrays): H2D of the batch and detokenisation inside the timed region",
@@ -496,7 +500,7 @@ def main() -> None:
                               "h2d_other_form": h2d_summary("grouped" if default_mode == "single" else "single"),
                               "h2d_note": "audio.pack_audio: host_fill = copying the request's rows into the pinned staging buffer, copy_span = first copy "
                                           "issued -> last copy done on the device timeline (the grouped form's span contains the fills between its copies); "
-                                          "both forms interleaved in this process, 4 timed runs each, medians"}
+                                          "both forms in this process, one block of 2 untimed + 5 timed runs each, medians"}
         log(f"end-to-end (H2D + detokenise): {line['end_to_end']['p50_latency_ms']:.1f} ms vs {line['p50_latency_ms']:.1f} ms resident "
             f"[{default_mode}: fill {line['end_to_end']['h2d']['host_fill_ms']:.1f} ms, copy span {line['end_to_end']['h2d']['copy_span_ms']:.1f} ms; "
             f"other form {line['end_to_end']['h2d_other_form']['p50_latency_ms']:.1f} ms]")
