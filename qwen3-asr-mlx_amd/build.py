@@ -19,6 +19,14 @@ if os.environ.get("Q3ASR_PACKED_F32", "0") != "1":
     FLAGS += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
+if os.environ.get("Q3ASR_KERNARG_PRELOAD", "1") != "0":
+    # gfx950 can hand the first 16 dwords of a kernel's arguments to the wave in SGPRs at dispatch instead of a scalar load from a
+    # cold cache at the top of every kernel: the decode step is 199 dependent launches of 4-14 us, and each one's first loads
+    # sit behind that load (tools/micro/adf_time.hip: qkv projection + decode attention 13.69 -> 13.32 us per layer at batch 1,
+    # 19.81 -> 19.03 at batch 32).  Code generation only: same results.  Q3ASR_KERNARG_PRELOAD=0 builds without it (A/B).
+    FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+
+
 def _stale(obj: Path, deps) -> bool:
     return (not obj.exists()) or any(d.stat().st_mtime > obj.stat().st_mtime for d in deps)
 

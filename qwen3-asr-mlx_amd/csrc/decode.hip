@@ -901,15 +901,24 @@ extern "C" int q3asr_embed_norm_x16(const int32_t* tok, const void* E, int V, vo
 // writes and for the transposing reads (same image as the prefill kernel, attn.hip)
 __device__ __forceinline__ int adm_off(int row, int ch) { return 256 * row + 16 * (ch ^ ((row & 7) << 1)); }   // round 4: conflict-free (attn.hip, TileImg<128>)
 
+#ifdef ADF_TIMING                     // tools/micro/adf_time.hip: wall_clock64 stamps of wave 0 of workgroup (0, 0, 0)
+__device__ long long g_adf_t[16];
+#define ADF_T(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_adf_t[i] = wall_clock64(); } while (0)
+#else
+#define ADF_T(i)
+#endif
 // NT: the cached keys / values are read with non-temporal loads (a cache that is streamed once per step).
 template <bool NT>
-__global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, int n_slabs, long slab_stride,
-                                                                const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
-                                                                const float* __restrict__ inv_freq, float eps,
+// Parameter order: the first 16 dwords are handed over in SGPRs at dispatch (kernarg preload, build.py); they are what the loads of
+// the prologue and of the first key tile need (slab addresses; the position and the cache rows), the rest is fetched beside them.
+__global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, long slab_stride,
+                                                                const int* __restrict__ pos_arr,
                                                                 bf16* __restrict__ k_cache, bf16* __restrict__ v_cache,
-                                                                const int* __restrict__ pos_arr, bf16* __restrict__ out16,
-                                                                int MT, int nh, int nkv, int Lmax, float scale,
-                                                                float* part, int* counters, int nc, int G) {
+                                                                int n_slabs, int nh, int nkv, int Lmax, int G, int nc, int MT,
+                                                                float scale, float eps,
+                                                                const bf16* __restrict__ qn_w, const bf16* __restrict__ kn_w,
+                                                                const float* __restrict__ inv_freq, bf16* __restrict__ out16,
+                                                                float* part, int* counters) {
     constexpr int NP = 8;                                             // partials merged per chunk: one per wave
     __shared__ __attribute__((aligned(16))) bf16 s_qb[2][128];
     __shared__ __attribute__((aligned(16))) bf16 s_k[128], s_v[128];
@@ -919,29 +928,23 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     __shared__ float s_part[ADF_LOCAL_MAX][ADF_PART];                  // per-chunk partials of a workgroup that owns the whole sequence
     extern __shared__ __attribute__((aligned(16))) char adm_tiles[];   // one 32-key V tile (8 KiB) per wave
     const int kvh = blockIdx.x, b = blockIdx.y;
-    const int pos = pos_arr[b];
-    const int L = pos + 1, n_active = (L + ADF_CHUNK - 1) / ADF_CHUNK;
-    const int c_begin = blockIdx.z * G, c_end = min(c_begin + G, n_active);   // this workgroup's chunks
-    if (c_begin >= n_active) return;                                  // whole workgroup: no barrier is skipped
-    const int n_groups = (n_active + G - 1) / G;                      // workgroups active for this (sequence, kv head)
-    const bool local = n_groups == 1 && n_active <= ADF_LOCAL_MAX;    // uniform: partials stay in LDS, no workspace round trip
-    const bool owner = c_end == n_active;                             // the last chunk holds the new token
+    ADF_T(0);
+    int pos = pos_arr[b];                                             // the head of the longest chain (position -> key tile -> scores): requested first,
+    asm volatile("" : "+s"(pos) :: "memory");                         // consumed below, after the slab loads have been issued
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i = lane & 15;
-    bf16* Kb = k_cache + ((long)b * nkv + kvh) * Lmax * 128;
-    bf16* Vb = v_cache + ((long)b * nkv + kvh) * Lmax * 128;
-    const int t0 = c_begin * ADF_CHUNK;
-    const int t_last = pos > 0 ? pos - 1 : 0;                         // tokens >= pos are never read from the cache
-    // The prologue's own loads go first: a wave's loads return in order, so the slab values must not queue behind the
-    // first 64 KiB of keys and values.
-    const bool pro = wave < 2 || (wave < 4 && owner);
+    // Round 5: the prologue's own loads are requested BEFORE the position is known.  The position decides which workgroups
+    // have work and which one owns the new token, and every later statement used to sit behind that test: a scalar load from a
+    // cold L2, then the slab loads, two dependent memory round trips in front of the norm (stamped, tools/micro/adf_time.hip:
+    // slabs summed 3.2 us after entry at batch 1, 5.3 us at batch 32).  The slab values of all four prologue waves do not
+    // depend on the position: waves 2 and 3 request their k / v columns whether or not this workgroup turns out to own the new
+    // token, and a workgroup without work leaves with 16 loads per lane outstanding (64 KiB per workgroup at most).  A wave's
+    // loads return in order, so they also stay ahead of the first 64 KiB of keys and values requested below.
     const int col = wave < 2 ? (2 * kvh + wave) * 128 : (wave == 2 ? (nh + kvh) * 128 : (nh + nkv + kvh) * 128);
     const float* src = qkv + (long)b * ld + col;
     const bf16* nw = wave < 2 ? qn_w : kn_w;
     float p1[8], p2[8];
-    bf16 nw1 = nw[lane], nw2 = nw[lane + 64];
-    const float freq = inv_freq[lane];
-    if (pro) {
+    if (wave < 4) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {                          // 8 slabs: 16 independent loads in flight
             const bool in = u < n_slabs;
@@ -949,6 +952,21 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             p2[u] = in ? src[u * slab_stride + lane + 64] : 0.f;
         }
     }
+    ADF_T(9);                                                  // the slab loads are issued
+    bf16 nw1 = nw[lane], nw2 = nw[lane + 64];
+    const float freq = inv_freq[lane];
+    ADF_T(10);
+    const int L = pos + 1, n_active = (L + ADF_CHUNK - 1) / ADF_CHUNK;
+    const int c_begin = blockIdx.z * G, c_end = min(c_begin + G, n_active);   // this workgroup's chunks
+    if (c_begin >= n_active) return;                                  // whole workgroup: no barrier is skipped
+    const int n_groups = (n_active + G - 1) / G;                      // workgroups active for this (sequence, kv head)
+    const bool local = n_groups == 1 && n_active <= ADF_LOCAL_MAX;    // uniform: partials stay in LDS, no workspace round trip
+    const bool owner = c_end == n_active;                             // the last chunk holds the new token
+    bf16* Kb = k_cache + ((long)b * nkv + kvh) * Lmax * 128;
+    bf16* Vb = v_cache + ((long)b * nkv + kvh) * Lmax * 128;
+    const int t0 = c_begin * ADF_CHUNK;
+    const int t_last = pos > 0 ? pos - 1 : 0;                         // tokens >= pos are never read from the cache
+    const bool pro = wave < 2 || (wave < 4 && owner);
     // One register set for a 32-key tile (K as A fragments, V rows on their way to LDS); the next tile's loads
     // are issued as soon as this tile's K fed the MFMAs and its V sits in LDS.  The first tile is issued here, ahead of
     // the prologue's arithmetic.
@@ -967,6 +985,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
         VR[it] = ADM_LD(reinterpret_cast<const u32x4*>(Vb + (long)min((TB) + (c_ >> 4), t_last) * 128 + 8 * (c_ & 15))); \
         }
     if (t0 + 32 * wave < min(L, t0 + ADF_CHUNK)) { ADM_LOAD(kR, vR, t0 + 32 * wave) }
+    ADF_T(11);                                                 // the position has arrived and the first key tile is requested
     if (pro) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -982,6 +1001,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             for (int u = 0; u < 8; ++u) { s1 += p1[u]; s2 += p2[u]; }
         }
         const float x1 = round_bf(s1), x2 = round_bf(s2);
+        ADF_T(1);                                                  // the slab values have arrived and are summed
         if (wave == 3) {
             const bf16 v1 = f2bf(x1), v2 = f2bf(x2);
             s_v[lane] = v1; s_v[lane + 64] = v2;
@@ -1004,7 +1024,9 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
     }
     // The first batch of cached keys/values does not depend on the prologue: it was issued above and is
     // in flight across this barrier.
+    ADF_T(2);                                                      // norm + RoPE done (wave 0)
     __syncthreads();
+    ADF_T(3);
     {
         // ---- S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_16x16x32_bf16, the two heads of this kv head being two
         // of the 16 query columns (prefill kernel's formulation, attn.hip).  Wave w owns the 32-key tiles w, w+8, ... of a
@@ -1094,7 +1116,9 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                 ADM_STAGE_QK(kR, vR, tb)
                 if (tb + 256 < ce) { ADM_LOAD(kR, vR, tb + 256) }
                 ADM_SOFTMAX_PV(tb)
+                ADF_T(4 + (tb - cb) / 256);                                // 4, 5: this wave's first / second tile done
             }
+            ADF_T(6);
             float l_tot = lane_xor16_sum(l_run);
             l_tot = lane_xor32_sum(l_tot);
             if (li < 2) {
@@ -1104,6 +1128,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                     *reinterpret_cast<f32x4*>(&s_acc[wave][li][16 * dt + 4 * g]) = o_[dt];
             }
             __syncthreads();
+            ADF_T(7);                                                      // every wave's partial is in LDS
             if (tid < 256) {
                 float Mx = -INFINITY, num = 0.f, den = 0.f;
                 for (int w = 0; w < 8; ++w) Mx = fmaxf(Mx, s_m[w][hm]);
@@ -1127,6 +1152,7 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                     }
                 }
             }
+            ADF_T(8);                                                      // merged and stored
             if (ce < t_endm) __syncthreads();                              // the partials are rewritten by the next chunk
         }
 #undef ADM_SOFTMAX_PV
@@ -1231,12 +1257,12 @@ extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_
     // and default-policy loads are faster there (batch 1: 162.4 vs 167.2 ms).
     const bool nt = (int64_t)B * nkv * Lmax * 512 > (16LL << 20);
     if (nt)
-        hipLaunchKernelGGL(attn_decode_fused_kernel<true>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
-                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
-                           nkv, Lmax, scale, part, counters, nc, G);
+        hipLaunchKernelGGL(attn_decode_fused_kernel<true>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, (long)slab_stride,
+                           pos, (bf16*)k_cache, (bf16*)v_cache, n_slabs, nh, nkv, Lmax, G, nc, MT, scale, eps, (const bf16*)qn_w, (const bf16*)kn_w, inv_freq,
+                           (bf16*)out, part, counters);
     else
-        hipLaunchKernelGGL(attn_decode_fused_kernel<false>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, n_slabs, (long)slab_stride,
-                           (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, eps, (bf16*)k_cache, (bf16*)v_cache, pos, (bf16*)out, MT, nh,
-                           nkv, Lmax, scale, part, counters, nc, G);
+        hipLaunchKernelGGL(attn_decode_fused_kernel<false>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, (long)slab_stride,
+                           pos, (bf16*)k_cache, (bf16*)v_cache, n_slabs, nh, nkv, Lmax, G, nc, MT, scale, eps, (const bf16*)qn_w, (const bf16*)kn_w, inv_freq,
+                           (bf16*)out, part, counters);
     return q3_check_launch("attn_decode_fused");
 }
