@@ -843,6 +843,49 @@ def test_attn_decode_fused_is_independent_of_batch_and_capacity(dev):
         assert torch.equal(one[0], full[j])
 
 
+@pytest.mark.parametrize("Lmax", [64, 576, 2560])
+def test_attn_decode_fused_never_uses_cache_rows_at_or_beyond_the_position(dev, Lmax):
+    """Rows of the cache at or beyond a sequence's position hold stale or never-written bits (a previous request's rows, a
+    failed row's NaNs).  The kernel must not USE them, whatever it fetches: with NaN, +-Inf and huge finite values in every
+    such row (keys and values), the outputs and the appended cache row are bit-identical to a run on a cache whose tail is
+    zero -- positions inside the first tile, at tile and chunk boundaries, and at the last row of the cache.  (Round 5 tried
+    requesting the first key tile before the position is known -- rows clamped to the capacity instead of to the last written
+    row; this test is what that form had to pass, and did.  It gained nothing: at batch 1 a workgroup's 43 loads per wave are
+    issue-bound on its CU's address path, not waiting for the position -- profiles/r05_decode_attention_stamps.txt.)"""
+    from qwen3_asr_mlx_amd import _lib, ops
+    nh, nkv, hd, S = 4, 2, 128, 2
+    qkvd = (nh + 2 * nkv) * hd
+    poss = [p for p in (0, 1, 5, 31, 32, 33, 63, 200, 255, 256, 257, 500, 1023, 1024, 1025, 2047, 2559) if p < Lmax] + [Lmax - 1]
+    B = len(poss)
+    parts = rnd((S, B, qkvd), dev, 170, 1.0, torch.float32)
+    qn, kn = rnd((hd,), dev, 171) + 1, rnd((hd,), dev, 172) + 1
+    inv = (1e6 ** (-torch.arange(64, dtype=torch.float32) / 64)).to(dev)
+    kc0, vc0 = rnd((B, nkv, Lmax, hd), dev, 173), rnd((B, nkv, Lmax, hd), dev, 174)
+    pos = torch.tensor(poss, dtype=torch.int32, device=dev)
+    poison = torch.tensor([float("nan"), float("inf"), float("-inf"), 3.0e38, -3.0e38], dtype=torch.bfloat16, device=dev)
+
+    def run(fill):
+        kc, vc = kc0.clone(), vc0.clone()
+        for b, p_ in enumerate(poss):
+            n = Lmax - p_
+            if fill == "zero":
+                kc[b, :, p_:], vc[b, :, p_:] = 0, 0
+            else:
+                pat = poison[(torch.arange(n * hd, device=dev) + b) % 5].reshape(n, hd)
+                kc[b, :, p_:], vc[b, :, p_:] = pat, pat
+        wsp = torch.zeros((_lib.load().q3asr_attn_decode_fused_workspace(B, nkv, Lmax) // 4,), dtype=torch.float32, device=dev)
+        o16 = torch.zeros((nh * hd // 32, ops.mt_of(B), 64, 8), dtype=torch.bfloat16, device=dev)
+        ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
+                 ops.ptr(kc), ops.ptr(vc), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
+        rows = torch.stack([torch.stack([kc[b, :, p_], vc[b, :, p_]]) for b, p_ in enumerate(poss)])      # the appended rows
+        return ops.from_x16(o16, B), rows
+
+    clean, rows_clean = run("zero")
+    dirty, rows_dirty = run("poison")
+    assert bool(torch.isfinite(clean.float()).all())
+    assert torch.equal(clean, dirty) and torch.equal(rows_clean, rows_dirty)
+
+
 # ----------------------------------------------------------------------------- fp8 weights (BASELINE.json configs[4])
 def test_fp8_row_quantisation_is_exact_in_bf16(dev):
     from qwen3_asr_mlx_amd import ops
