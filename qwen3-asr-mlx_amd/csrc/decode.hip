@@ -1049,6 +1049,8 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
                 _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                              \
                     const int c_ = lane + 64 * it;                                                              \
                     if ((TB) + (c_ >> 4) == pos) VR[it] = *reinterpret_cast<const u32x4*>(s_v + 8 * (c_ & 15)); \
+                    else if ((TB) + (c_ >> 4) > pos) VR[it] = u32x4{0u, 0u, 0u, 0u};   /* keys beyond the position weigh 0, but the rows fetched in \
+                        their place (row t_last: at position 0 a row that was never written) may hold NaN, and 0 x NaN is not 0 */ \
                 }                                                                                               \
             }                                                                                                   \
             _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                  \
@@ -1110,6 +1112,8 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
             for (int dt = 0; dt < 8; ++dt) o_[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
             float m_run = -INFINITY, l_run = 0.f;
             int tb = cb + 32 * wave;
+            // (Round 5, measured and not kept: the keys of a wave's next-but-one tile in flight too -- a second register set, 220 -> 254
+            // VGPRs, same bits; tools/ab_step.py in one process: 1480.2 -> 1484.0 us per step at batch 32, 1118.1 -> 1129.8 at batch 1.)
             if (cb != t0 && tb < ce) { ADM_LOAD(kR, vR, tb) }             // the first chunk's first tile is already in flight
             for (; tb < ce; tb += 256) {
                 f32x4 sc_[2];

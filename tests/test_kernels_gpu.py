@@ -848,7 +848,8 @@ def test_attn_decode_fused_never_uses_cache_rows_at_or_beyond_the_position(dev, 
     """Rows of the cache at or beyond a sequence's position hold stale or never-written bits (a previous request's rows, a
     failed row's NaNs).  The kernel must not USE them, whatever it fetches: with NaN, +-Inf and huge finite values in every
     such row (keys and values), the outputs and the appended cache row are bit-identical to a run on a cache whose tail is
-    zero -- positions inside the first tile, at tile and chunk boundaries, and at the last row of the cache.  (Round 5 tried
+    zero -- position 0 (where the kernel's row clamp lands on a row that was never written: this test found that case unguarded),
+    positions inside the first tile, at tile and chunk boundaries, and at the last row of the cache.  (Round 5 tried
     requesting the first key tile before the position is known -- rows clamped to the capacity instead of to the last written
     row; this test is what that form had to pass, and did.  It gained nothing: at batch 1 a workgroup's 43 loads per wave are
     issue-bound on its CU's address path, not waiting for the position -- profiles/r05_decode_attention_stamps.txt.)"""

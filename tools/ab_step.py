@@ -61,7 +61,7 @@ with torch.cuda.stream(side):
         for o, v in sw:
             _lib.load().q3asr_set_option(o, v)
         graphs[name] = dec._capture(ws, cache, sampling, steps)
-    for o in (1, 2):
+    for o in (1, 2, 3, 4, 5):
         _lib.load().q3asr_set_option(o, 1)
     ts = {name: [] for name, _ in arms}
     for rnd in range(rounds + 1):
