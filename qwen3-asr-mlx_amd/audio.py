@@ -204,6 +204,55 @@ def release_staging() -> None:
 PACK_MODE = "single"
 PACK_STATS: Optional[dict] = None      # set to a dict to have the next pack_audio call record its host times and copy events
 
+# The staging fill runs on a small thread pool of its own, never on torch's intra-op pool.  Round 5 found the cause of the
+# 20-35 ms `end_to_end` spikes (and of the round-4 driver's +31 ms): `tensor[...] = from_numpy(row)` parallelises a 2 MB row copy over
+# torch's default thread count -- 128 on the GPU boxes, whose container is allowed 16 CPUs (cgroup cpu.max 1600000 100000) -- and 128
+# spinning threads exhaust the container's CPU quota, so the kernel parks the whole process for the rest of the 100 ms period
+# (cpu.stat: nr_throttled, throttled_usec).  Rows are copied with numpy (which releases the GIL) by at most 8 workers, fewer if
+# the affinity mask or the cgroup quota is smaller.
+_fill_pool = None
+_fill_pool_lock = threading.Lock()
+
+
+def _fill_workers() -> int:
+    import os
+    n = 8
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        n = min(n, os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _fill_rows(host_np, batch, lens, lmax, i0: int, i1: int) -> None:
+    """Rows i0..i1-1 of the request into the pinned buffer (a numpy view of it), zero tails included."""
+    global _fill_pool
+    with _fill_pool_lock:
+        if _fill_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _fill_pool = ThreadPoolExecutor(max_workers=_fill_workers(), thread_name_prefix="q3asr-fill")
+        pool = _fill_pool
+
+    def rows(a: int, b: int) -> None:
+        for i in range(a, b):
+            np.copyto(host_np[i, : lens[i]], batch[i], casting="unsafe")
+            if lens[i] < lmax:
+                host_np[i, lens[i]:] = 0.0
+
+    w = min(pool._max_workers, i1 - i0)
+    if w <= 1:
+        rows(i0, i1)
+        return
+    step = (i1 - i0 + w - 1) // w
+    for f in [pool.submit(rows, a, min(a + step, i1)) for a in range(i0, i1, step)]:
+        f.result()
+
 
 def pack_audio(batch: Sequence[np.ndarray], device, mode: Optional[str] = None):
     """Host list of 1-D float32 arrays -> (padded device tensor [B][Lmax], lens device, lens host).
@@ -234,6 +283,7 @@ def pack_audio(batch: Sequence[np.ndarray], device, mode: Optional[str] = None):
     if ev is not None:
         ev.synchronize()                                   # the previous request's H2D copy has read the buffer
     host = flat[:n].view(len(batch), lmax)
+    host_np = host.numpy()                                 # the same pinned bytes
     dev = torch.empty((len(batch), lmax), dtype=torch.float32, device=dev_t)
     t1 = time.perf_counter()
     stream = torch.cuda.current_stream(dev.device)
@@ -246,10 +296,7 @@ def pack_audio(batch: Sequence[np.ndarray], device, mode: Optional[str] = None):
     for i0 in range(0, len(batch), group):
         i1 = min(i0 + group, len(batch))
         f0 = time.perf_counter()
-        for i in range(i0, i1):
-            host[i, : lens[i]] = torch.from_numpy(np.ascontiguousarray(batch[i], dtype=np.float32))
-            if lens[i] < lmax:
-                host[i, lens[i]:] = 0.0
+        _fill_rows(host_np, batch, lens, lmax, i0, i1)
         f1 = time.perf_counter()
         if first and e0 is not None:
             e0.record(stream)
