@@ -298,6 +298,15 @@ def main() -> None:
     from qwen3_asr_mlx_amd import _lib, synth
     from qwen3_asr_mlx_amd.config import ModelConfig
 
+    # The GPU boxes show 256 CPUs, torch takes 128 intra-op threads, the container's cgroup allows 16: a 128-thread CPU op (weight
+    # initialisation, the CPU baseline's GEMMs) exhausts the quota and the kernel parks the WHOLE process, timed regions included, for
+    # the rest of the scheduler period (cpu.stat nr_throttled).  The harness keeps torch inside the quota.
+    try:
+        quota_, period_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota_ != "max":
+            torch.set_num_threads(max(1, min(torch.get_num_threads(), int(quota_) // int(period_))))
+    except (OSError, ValueError):
+        pass
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
