@@ -74,7 +74,7 @@ int q3asr_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, int 
 /* Tuning / test hook: pin the GEMM kernel (0 = automatic choice, 64 = 64x64 tile, 128 = 128x128 tile, 8 = 256x256 8-phase LDS-DMA
  * pipeline where its preconditions hold, 224 / 208 = the same pipeline on 224x256 / 208x256 tiles).  All kernels give bit-identical results. */
 int q3asr_gemm_force_kernel(int mode);
-/* Diagnostic: 0 = every sub-tile of the 8-phase kernels takes the general (bounds-tested) epilogue, 1 = interior sub-tiles take the short one (default). Same bits either way; returns the previous setting. Used by tools/ab_gemm_epilogue.py */
+/* Diagnostic: 0 = every sub-tile of the 8-phase kernels takes the general (bounds-tested) epilogue, 1 = interior sub-tiles take the short one, 2 (default) = ... and the plain bf16 GEMM reads a sub-tile's residual rows one 16-row block ahead of their use. Same bits in every setting; returns the previous one. Used by tools/ab_gemm_epilogue.py */
 int q3asr_gemm_set_interior(int on);
 /* Diagnostic: switches between two launch forms with identical results, for A/B measurements in one process (tools/ab_step.py,
  * tools/bench_head.py).  Every option defaults to 1; returns the previous value, or -1 for an unknown option.  A captured

@@ -118,7 +118,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // (read as whole rows too) after it; arithmetic and rounding points are those of gemm_epilogue, so results are bit-identical.
 // Preconditions (checked on the host, else gemm_epilogue): N % 8 == 0, ldo / ldres multiples of 8, 16-byte aligned bases.
 // ---------------------------------------------------------------------------
-template <int MI = 8, int MIA = MI>   // MI: 16-row blocks per wave: 8 (128 rows), 7 (112) or 6 (96: the second wave row of a 208-row tile); MIA: blocks the array holds
+// PRE: the residual-ahead form exists (plain bf16 GEMM only: the fp8 and conv variants have no 16-32 registers to spare in their epilogues).
+template <int MI = 8, int MIA = MI, bool PRE = false>   // MI: 16-row blocks per wave: 8 (128 rows), 7 (112) or 6 (96: the second wave row of a 208-row tile); MIA: blocks the array holds
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[4][MIA], int m_base, int n_base, int n0, int wn,
                                                   char* st, int lane) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -129,7 +130,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     if (p.act == 2) {                                                     // SwiGLU: 16 rows x 32 output columns per block (64-byte rows)
         const int n_out0 = (n0 >> 1) + wn * 32;
         const int rr = lane >> 2, rc = lane & 3;
-        if (p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map) {   // interior sub-tile: see the bf16 path below
+        if (p.lds_epi >= 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map) {   // interior sub-tile: see the bf16 path below
             const unsigned voff = (unsigned)rr * (unsigned)p.ldo + (unsigned)(n_out0 + 8 * rc);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -183,15 +184,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         // and has no row map stores through a uniform row pointer + one 32-bit lane offset, without per-row bound tests and
         // 64-bit address chains: a wave64 VALU instruction takes ~4 cycles on this part (tools/pmc_kernel.sh), and the general
         // path spends a few hundred of them per tile on addresses.  Same values, same rounding points.
-        if (p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {
+        if (p.lds_epi >= 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {
             const unsigned voff = (unsigned)(lane >> 3) * (unsigned)p.ldo + (unsigned)(n_base + 8 * rc);
             const unsigned roff = (unsigned)(lane >> 3) * (unsigned)p.ldres + (unsigned)(n_base + 8 * rc);
             f32x4 bv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n_base + j * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // Round 5: the residual rows of block i + 1 are requested before block i is transposed and stored (lds_epi == 3).  Read
+            // where they are used, every 16-row block paid a memory round trip of its own -- 6 to 8 per sub-tile, the "burst" the
+            // round-4 stamps showed as a 17-19 us epilogue on the tiles with a residual.  Same values, same adds.
+            const bool ahead = PRE && p.lds_epi == 3 && p.res_kind == 2;
+            bf16x8 rn[2][2];
+            auto load_res = [&](int i, bf16x8 (&r)[2]) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) r[h] = *reinterpret_cast<const bf16x8*>((const bf16*)p.res + (long)(m_base + i * 16 + 8 * h) * p.ldres + roff);
+            };
+            if (ahead) load_res(0, rn[0]);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 char* blk = st + (i & 1) * 2048;
+                if (ahead && i + 1 < MI) load_res(i + 1, rn[(i + 1) & 1]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = acc[j][i];
@@ -212,7 +224,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
                     bf16x8 v = *reinterpret_cast<const bf16x8*>(blk + rr * 128 + ((rc ^ (rr & 7)) << 4));
                     const long mrow = m_base + i * 16 + 8 * h;                   // uniform
                     if (p.res_kind == 2) {                                   // MLX bf16 add: both operands bf16, sum rounded once
-                        const bf16x8 rv = *reinterpret_cast<const bf16x8*>((const bf16*)p.res + mrow * p.ldres + roff);
+                        const bf16x8 rv = ahead ? rn[i & 1][h] : *reinterpret_cast<const bf16x8*>((const bf16*)p.res + mrow * p.ldres + roff);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rv[e]));
                     }
@@ -264,14 +276,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     // fp32 out (+ optional fp32 residual): 16 rows x 64 columns per block (256-byte rows), one block in flight
     const int rc = lane & 15;
     const int n = n_base + 4 * rc;
-    if (p.lds_epi == 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {   // interior sub-tile: see the bf16 path above
+    if (p.lds_epi >= 2 && m_base + 16 * MI <= p.M && n_base + 64 <= p.N && !p.row_map && p.res_mod <= 0) {   // interior sub-tile: see the bf16 path above
         const unsigned voff = (unsigned)(lane >> 4) * (unsigned)p.ldo + (unsigned)(n_base + 4 * rc);
         const unsigned roff = (unsigned)(lane >> 4) * (unsigned)p.ldres + (unsigned)(n_base + 4 * rc);
         f32x4 bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n_base + j * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool ahead = PRE && p.lds_epi == 3 && p.res_kind == 1;    // residual rows one block ahead: see the bf16 path above
+        f32x4 rn[2][4];
+        auto load_res = [&](int i, f32x4 (&r)[4]) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) r[h] = *reinterpret_cast<const f32x4*>((const float*)p.res + (long)(m_base + i * 16 + 4 * h) * p.ldres + roff);
+        };
+        if (ahead) load_res(0, rn[0]);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            if (ahead && i + 1 < MI) load_res(i + 1, rn[(i + 1) & 1]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[j][i];
@@ -287,7 +307,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
                 const int rr = (lane >> 4) + 4 * h;
                 f32x4 v = *reinterpret_cast<const f32x4*>(st + rr * 256 + ((rc ^ rr) << 4));
                 const long mrow = m_base + i * 16 + 4 * h;                       // uniform
-                if (p.res_kind == 1) v += *reinterpret_cast<const f32x4*>((const float*)p.res + mrow * p.ldres + roff);
+                if (p.res_kind == 1) v += ahead ? rn[i & 1][h] : *reinterpret_cast<const f32x4*>((const float*)p.res + mrow * p.ldres + roff);
                 *reinterpret_cast<f32x4*>((float*)p.out + mrow * p.ldo + voff) = v;
             }
         }
@@ -917,7 +937,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
                 }
             }
             // all three variants (plain, conv, fp8) carry both the interior and the general path
-            if (p.lds_epi) gemm_epilogue_lds<MIW>(p, acc, m_wave, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
+            if (p.lds_epi) gemm_epilogue_lds<MIW, MIW, CONV == 0>(p, acc, m_wave, n0 + wc * 64, n0, wc, smem8 + 8 * G8_SLOT + wave * 4096, lane);
             else gemm_epilogue<MIW>(p, acc, m_wave, n0 + wc * 64, n0, wc, g, li);
             G8_STAMP();                                                     // 3 + 2t: epilogue of tile t issued
             v += gridDim.x;
@@ -932,8 +952,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmParams p, int 
 }
 
 static int g_gemm_mode = 0;                                  // q3asr_gemm_force_kernel
-static int g_gemm_interior = 1;                              // q3asr_gemm_set_interior (A/B hook): 0 = every tile takes the general epilogue
-extern "C" int q3asr_gemm_set_interior(int on) { int was = g_gemm_interior; g_gemm_interior = on ? 1 : 0; return was; }
+static int g_gemm_interior = 2;                              // q3asr_gemm_set_interior (A/B hook): 0 = every tile takes the general epilogue,
+                                                             // 1 = interior sub-tiles take the short one, 2 = ... and read their residual rows one block ahead
+extern "C" int q3asr_gemm_set_interior(int on) { int was = g_gemm_interior; g_gemm_interior = on < 0 ? 0 : (on > 2 ? 2 : on); return was; }
 static unsigned long long* g_gemm_stamp = nullptr;           // q3asr_gemm_set_stamp
 
 // Diagnostic hook: workgroup 0 of every following 8-phase launch writes up to 16 wall_clock64() stamps (100 MHz) to `buf`
@@ -986,7 +1007,7 @@ static void gemm_launch(const GemmParams& p, bool conv, hipStream_t s, int force
                      (p.res_kind == 0 || (p.ldres % 8 == 0 && ((uintptr_t)p.res & 15) == 0)) &&
                      (!p.bias || ((uintptr_t)p.bias & 15) == 0);
         // 2: interior sub-tiles may take the short epilogue (32-bit lane offsets: the output and the residual must span < 4 Gi elements)
-        if (p8.lds_epi && g_gemm_interior && (long)p.M * p.ldo < (1L << 32) && (p.res_kind == 0 || (long)p.M * p.ldres < (1L << 32))) p8.lds_epi = 2;
+        if (p8.lds_epi && g_gemm_interior && (long)p.M * p.ldo < (1L << 32) && (p.res_kind == 0 || (long)p.M * p.ldres < (1L << 32))) p8.lds_epi = 1 + g_gemm_interior;
         static std::atomic<bool> attr8{false};
         if (!attr8) {
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS);
@@ -1117,7 +1138,7 @@ extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale,
     else Q3_REQUIRE(ldo % 8 == 0 && ldo >= N, "gemm_fp8: ldo=%ld must be >= N and a multiple of 8", (long)ldo);
     Q3_REQUIRE(((uintptr_t)out & 15) == 0 && ((uintptr_t)w_scale & 15) == 0 && (res_kind == 0 || (ldres % 8 == 0 && ((uintptr_t)res & 15) == 0)),
                "gemm_fp8: out / w_scale / res must be 16-byte aligned");
-    p.lds_epi = (g_gemm_interior && (long)M * ldo < (1L << 32) && (res_kind == 0 || (long)M * ldres < (1L << 32))) ? 2 : 1;   // as in gemm_launch
+    p.lds_epi = (g_gemm_interior && (long)M * ldo < (1L << 32) && (res_kind == 0 || (long)M * ldres < (1L << 32))) ? 1 + g_gemm_interior : 1;   // as in gemm_launch
     const unsigned tiles256 = (unsigned)((M + G2_T - 1) / G2_T) * (unsigned)((N + G2_T - 1) / G2_T);
     static std::atomic<bool> attr{false};
     if (!attr) {

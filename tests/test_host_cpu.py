@@ -48,7 +48,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     # the A/B switches between launch forms: previous value back, unknown ids refused
     assert h.q3asr_set_option(1, 0) == 1 and h.q3asr_set_option(1, 1) == 0 and h.q3asr_set_option(2, 1) == 1
     assert h.q3asr_set_option(7, 1) == -1 and b"unknown option" in h.q3asr_last_error()
-    assert h.q3asr_gemm_set_interior(1) == 1
+    assert h.q3asr_gemm_set_interior(1) == 2 and h.q3asr_gemm_set_interior(2) == 1      # default 2: interior sub-tiles, residual rows read one block ahead
 
 
 def test_filterbank_and_prompt_and_splitter_match_fixtures():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the 8-phase GEMM's interior-tile epilogue in one process (q3asr_gemm_set_interior): the encoder / prefill GEMM shapes
+"""A/B of the 8-phase GEMM's interior-tile epilogue (and, round 5, of its residual-ahead form) in one process (q3asr_gemm_set_interior 0 / 1 / 2): the encoder / prefill GEMM shapes
 at batch 32, interleaved rounds, HIP events around 20 back-to-back launches per arm; operands rotated over 4 buffer sets."""
 import ctypes as C
 import sys
@@ -36,10 +36,10 @@ for name, M, N, K, kw in shapes:
             ops.gemm(A, W, M, N, K, out, res=res, res_kind=2, ldres=N)
         else:
             ops.gemm(A, W, M, N, K, out, bias=bias, act=kw.get("act", 0))
-    ts = {0: [], 1: []}
+    ts = {0: [], 1: [], 2: []}
     outs = {}
     for rnd in range(6):
-        for arm in (1, 0):
+        for arm in (2, 1, 0):
             lib.q3asr_gemm_set_interior(arm)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -51,7 +51,8 @@ for name, M, N, K, kw in shapes:
                 ts[arm].append(e0.elapsed_time(e1) * 1000 / 20)
             if not kw.get("res32"):
                 outs[arm] = sets[3][3].clone()
-    lib.q3asr_gemm_set_interior(1)
-    same = "" if kw.get("res32") else f"  same bits: {bool(torch.equal(outs[0], outs[1]))}"
+    lib.q3asr_gemm_set_interior(2)
+    same = "" if kw.get("res32") else f"  same bits: {bool(torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]))}"
     med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
-    print(f"{name:28s} general {med(ts[0]):7.1f} us   interior {med(ts[1]):7.1f} us   ({100 * (med(ts[1]) / med(ts[0]) - 1):+.1f} %){same}")
+    print(f"{name:28s} general {med(ts[0]):7.1f} us   interior {med(ts[1]):7.1f} us   ({100 * (med(ts[1]) / med(ts[0]) - 1):+.1f} %)   "
+          f"+ residual rows one block ahead {med(ts[2]):7.1f} us   ({100 * (med(ts[2]) / med(ts[1]) - 1):+.1f} % vs interior){same}")
