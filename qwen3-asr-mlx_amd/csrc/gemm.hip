@@ -193,6 +193,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
             // Round 5: the residual rows of block i + 1 are requested before block i is transposed and stored (lds_epi == 3).  Read
             // where they are used, every 16-row block paid a memory round trip of its own -- 6 to 8 per sub-tile, the "burst" the
             // round-4 stamps showed as a 17-19 us epilogue on the tiles with a residual.  Same values, same adds.
+            // (Two fp32 / four bf16 blocks ahead -- the registers exist in the 224- and 208-row variants -- measured the same as one: encoder out
+            // 41.3-41.6 vs 41.3-41.5 us, fc2 97.4 vs 98.3, prefill o 101 vs 102: after the first block the stores and transposes set the pace.)
             const bool ahead = PRE && p.lds_epi == 3 && p.res_kind == 2;
             bf16x8 rn[2][2];
             auto load_res = [&](int i, bf16x8 (&r)[2]) {
