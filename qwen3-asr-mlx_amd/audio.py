@@ -236,8 +236,9 @@ def _fill_rows(host_np, batch, lens, lmax, i0: int, i1: int) -> None:
     with _fill_pool_lock:
         if _fill_pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            _fill_pool = ThreadPoolExecutor(max_workers=_fill_workers(), thread_name_prefix="q3asr-fill")
-        pool = _fill_pool
+            n = _fill_workers()
+            _fill_pool = (ThreadPoolExecutor(max_workers=n, thread_name_prefix="q3asr-fill"), n)
+        pool, workers = _fill_pool
 
     def rows(a: int, b: int) -> None:
         for i in range(a, b):
@@ -245,7 +246,7 @@ def _fill_rows(host_np, batch, lens, lmax, i0: int, i1: int) -> None:
             if lens[i] < lmax:
                 host_np[i, lens[i]:] = 0.0
 
-    w = min(pool._max_workers, i1 - i0)
+    w = min(workers, i1 - i0)
     if w <= 1:
         rows(i0, i1)
         return
