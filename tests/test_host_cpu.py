@@ -385,3 +385,25 @@ def test_kv_cache_update_semantics_on_the_host():
         cache.update(0, k2, v2[:, :, :0])
     with pytest.raises(ValueError):
         cache.update(0, mk(1)[:1], mk(1)[:1])                               # batch 1 on a cache holding batch 2
+
+
+def test_staging_fill_rows_and_worker_bound():
+    """audio._fill_rows: the request's rows land in the staging buffer (any float dtype cast to float32, ragged lengths, zero tails,
+    sub-ranges), on a private pool whose size never exceeds 8, the affinity mask or the container's CPU quota -- the fill must not
+    run on torch's intra-op pool (128 threads against a 16-CPU cgroup on the GPU boxes: DESIGN.md section 0)."""
+    import os
+    from qwen3_asr_mlx_amd import audio
+    n = audio._fill_workers()
+    assert 1 <= n <= 8 and n <= len(os.sched_getaffinity(0))
+    rng = np.random.default_rng(5)
+    lens = [1000, 37, 0, 999, 512, 1000, 1, 640, 77]
+    clips = [rng.standard_normal(k).astype(np.float64 if i % 3 == 0 else np.float32) for i, k in enumerate(lens)]
+    lmax = max(lens)
+    host = np.full((len(lens), lmax), 7.0, dtype=np.float32)
+    audio._fill_rows(host, clips, lens, lmax, 0, len(lens))
+    for i, k in enumerate(lens):
+        assert np.array_equal(host[i, :k], clips[i].astype(np.float32)) and not host[i, k:].any()
+    host[:] = 7.0
+    audio._fill_rows(host, clips, lens, lmax, 3, 5)                    # a group of rows (the grouped staging form)
+    assert (host[:3] == 7.0).all() and (host[5:] == 7.0).all() and np.array_equal(host[4, :512], clips[4])
+    assert audio._fill_pool is not None and audio._fill_pool[1] == n
