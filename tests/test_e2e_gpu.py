@@ -997,3 +997,21 @@ def test_queue_front_door_equals_transcribe(dev, small, encode_thread, async_adm
     assert srv.stats["admissions"] >= len(xs) + 2 and srv.stats["rows"] == 4
     with pytest.raises(RuntimeError):
         srv.submit(xs[0])
+
+
+def test_batch_of_40_rows_uses_three_m_tiles_and_rows_equal_their_single_runs(dev, small):
+    """33-48 decode rows run on three m-tiles (csrc/decode.hip q3_mt_of, round 5; the 40 segments of BASELINE configs[4]): through
+    the whole product path (graph decode) the rows of a 40-row batch equal their single runs bit for bit, and the skinny3 decode
+    GEMMs (their own three-m-tile instantiations) produce tokens that agree with skinny4's up to near-ties."""
+    import qwen3_asr_mlx_amd as q
+    from qwen3_asr_mlx_amd import ops, synth
+    cfg, state, model = small
+    assert ops.mt_of(40) == 3
+    xs = [signal("speechlike", 16000 + 800 * (i % 7), seed=100 + i) for i in range(40)]
+    batched = model.generate_tokens(xs, [8] * 40, "English")
+    for i in (0, 17, 33, 39):
+        assert model.generate_tokens([xs[i]], [8], "English")[0] == batched[i], i
+    other = q.Qwen3ASR.from_state_dict(cfg, state, synth.SyntheticTokenizer(), dev, decode_gemm="sk3")
+    sk3 = other.generate_tokens(xs, [8] * 40, "English")
+    agree = sum(a == b for r3, r4 in zip(sk3, batched) for a, b in zip(r3, r4))
+    assert all(r3[0] == r4[0] for r3, r4 in zip(sk3, batched)) and agree >= 0.9 * 40 * 8
