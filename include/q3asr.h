@@ -83,6 +83,7 @@ int q3asr_gemm_set_interior(int on);
 #define Q3ASR_OPT_HEAD_STREAM 2     /* tied head (bf16, K = 2048, geometry 2/8/8, <= 32 rows): one workgroup per CU walking its tile groups */
 #define Q3ASR_OPT_ATTN_XCD_ORDER 3  /* attn_fwd: workgroups that read one kv head's K/V run on one XCD (0: the (query tile, head, segment) grid order) */
 #define Q3ASR_OPT_SAMPLER_RESIDENT 4 /* sample_step with temperature > 0: rows of <= 155,648 logits are held in registers / LDS across the passes (0: every pass re-reads the row) */
+#define Q3ASR_OPT_ATTN_HALF_WG 5 /* attn_decode_fused with more workgroups than CUs (33-64 rows): four-wave workgroups, two per CU, each wave computing two of the eight per-wave partials (0: eight-wave workgroups in two rounds) */
 int q3asr_set_option(int option, int value);
 /* Diagnostic: workgroup 0 of the following 8-phase launches records wall_clock64() stamps into buf (16 x u64 device memory; NULL = off) */
 int q3asr_gemm_set_stamp(void* buf);

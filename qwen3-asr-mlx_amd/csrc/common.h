@@ -25,6 +25,7 @@ extern int g_q3_option[8];
 #define Q3ASR_OPT_HEAD_STREAM 2
 #define Q3ASR_OPT_ATTN_XCD_ORDER 3
 #define Q3ASR_OPT_SAMPLER_RESIDENT 4
+#define Q3ASR_OPT_ATTN_HALF_WG 5
 int q3_check_launch(const char* what);
 
 #define Q3_REQUIRE(cond, ...)                 \

@@ -19,7 +19,7 @@ extern "C" const char* q3asr_arch(void) { return "gfx950"; }
 // Diagnostic switches (tools/ab_step.py): every option selects between two launch forms with identical results; all default to 1.
 int g_q3_option[8] = {1, 1, 1, 1, 1, 1, 1, 1};
 extern "C" int q3asr_set_option(int option, int value) {
-    if (option != Q3ASR_OPT_HEAD_XCD_MAP && option != Q3ASR_OPT_HEAD_STREAM && option != Q3ASR_OPT_ATTN_XCD_ORDER && option != Q3ASR_OPT_SAMPLER_RESIDENT) { q3asr_set_error("q3asr_set_option: unknown option %d", option); return -1; }
+    if (option != Q3ASR_OPT_HEAD_XCD_MAP && option != Q3ASR_OPT_HEAD_STREAM && option != Q3ASR_OPT_ATTN_XCD_ORDER && option != Q3ASR_OPT_SAMPLER_RESIDENT && option != Q3ASR_OPT_ATTN_HALF_WG) { q3asr_set_error("q3asr_set_option: unknown option %d", option); return -1; }
     const int was = g_q3_option[option];
     g_q3_option[option] = value ? 1 : 0;
     return was;

@@ -908,10 +908,15 @@ __device__ long long g_adf_t[16];
 #define ADF_T(i)
 #endif
 // NT: the cached keys / values are read with non-temporal loads (a cache that is streamed once per step).
-template <bool NT>
+// W4: a workgroup of FOUR waves computes the eight per-wave partials of a chunk -- wave w those of the "logical" waves w and w + 4,
+// one after the other, each with its own online-softmax state, written to the same s_m / s_l / s_acc slots and merged by the
+// same code: bit-identical to the eight-wave form.  Round 5, for launches with more workgroups than CUs (33-64 rows: 264-512
+// (sequence, kv head) pairs): at 220 VGPRs an eight-wave workgroup owns its CU, so 320 of them ran as a full round and a
+// quarter-filled one (23.0 us per launch at 40 rows against 13.6 at 32); two four-wave workgroups share a CU.
+template <bool NT, bool W4>
 // Parameter order: the first 16 dwords are handed over in SGPRs at dispatch (kernarg preload, build.py); they are what the loads of
 // the prologue and of the first key tile need (slab addresses; the position and the cache rows), the rest is fetched beside them.
-__global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, long slab_stride,
+__global__ __launch_bounds__(W4 ? 256 : 512, 2) void attn_decode_fused_kernel(const float* __restrict__ qkv, long ld, long slab_stride,
                                                                 const int* __restrict__ pos_arr,
                                                                 bf16* __restrict__ k_cache, bf16* __restrict__ v_cache,
                                                                 int n_slabs, int nh, int nkv, int Lmax, int G, int nc, int MT,
@@ -1107,29 +1112,35 @@ __global__ __launch_bounds__(512, 2) void attn_decode_fused_kernel(const float* 
         float* mym = part + (((long)b * nkv + kvh) * nc) * ADF_PART;
         for (int cb = t0; cb < t_endm; cb += ADF_CHUNK) {                 // chunks of this workgroup
             const int ce = min(t_endm, cb + ADF_CHUNK);
-            f32x4 o_[8];
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) o_[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float m_run = -INFINITY, l_run = 0.f;
-            int tb = cb + 32 * wave;
+            if (cb != t0 && cb + 32 * wave < ce) { ADM_LOAD(kR, vR, cb + 32 * wave) }   // the first chunk's first tile is already in flight
             // (Round 5, measured and not kept: the keys of a wave's next-but-one tile in flight too -- a second register set, 220 -> 254
             // VGPRs, same bits; tools/ab_step.py in one process: 1480.2 -> 1484.0 us per step at batch 32, 1118.1 -> 1129.8 at batch 1.)
-            if (cb != t0 && tb < ce) { ADM_LOAD(kR, vR, tb) }             // the first chunk's first tile is already in flight
-            for (; tb < ce; tb += 256) {
-                f32x4 sc_[2];
-                ADM_STAGE_QK(kR, vR, tb)
-                if (tb + 256 < ce) { ADM_LOAD(kR, vR, tb + 256) }
-                ADM_SOFTMAX_PV(tb)
-                ADF_T(4 + (tb - cb) / 256);                                // 4, 5: this wave's first / second tile done
-            }
-            ADF_T(6);
-            float l_tot = lane_xor16_sum(l_run);
-            l_tot = lane_xor32_sum(l_tot);
-            if (li < 2) {
-                if (g == 0) { s_m[wave][li] = m_run; s_l[wave][li] = l_tot; }
 #pragma unroll
-                for (int dt = 0; dt < 8; ++dt)
-                    *reinterpret_cast<f32x4*>(&s_acc[wave][li][16 * dt + 4 * g]) = o_[dt];
+            for (int half = 0; half < (W4 ? 2 : 1); ++half) {             // W4: logical waves `wave` and `wave + 4`, in that order
+                const int lw = wave + 4 * half;
+                f32x4 o_[8];
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) o_[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                float m_run = -INFINITY, l_run = 0.f;
+                for (int tb = cb + 32 * lw; tb < ce; tb += 256) {
+                    f32x4 sc_[2];
+                    ADM_STAGE_QK(kR, vR, tb)
+                    // the next tile of this physical wave: the logical wave's own next one, or (W4) the other logical wave's first
+                    int nxt = tb + 256;
+                    if (W4 && half == 0 && nxt >= ce) nxt = cb + 32 * (lw + 4);
+                    if ((!W4 || half == 0 || tb + 256 < ce) && nxt < ce) { ADM_LOAD(kR, vR, nxt) }
+                    ADM_SOFTMAX_PV(tb)
+                    ADF_T(4 + ((tb - cb) >> 8 & 1));                       // 4, 5: this wave's first / second tile done
+                }
+                ADF_T(6);
+                float l_tot = lane_xor16_sum(l_run);
+                l_tot = lane_xor32_sum(l_tot);
+                if (li < 2) {
+                    if (g == 0) { s_m[lw][li] = m_run; s_l[lw][li] = l_tot; }
+#pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+                        *reinterpret_cast<f32x4*>(&s_acc[lw][li][16 * dt + 4 * g]) = o_[dt];
+                }
             }
             __syncthreads();
             ADF_T(7);                                                      // every wave's partial is in LDS
@@ -1252,21 +1263,25 @@ extern "C" int q3asr_attn_decode_fused(const float* qkv_slab, int64_t ld, int n_
     const int G = adf_chunks_per_wg(B * nkv, nc);
     static std::atomic<bool> attr{false};
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
-        (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+        (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+        (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8192);
+        (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8192);
+        (void)hipFuncSetAttribute((const void*)attn_decode_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8192);
         attr = true;
     }
     // K/V larger than the caches can keep from one step to the next are streamed with non-temporal loads (batch 32, 512-token
     // capacity: 67 MB per layer; 252 -> 250 ms per request); a small cache stays resident in L2 / Infinity Cache between steps
     // and default-policy loads are faster there (batch 1: 162.4 vs 167.2 ms).
     const bool nt = (int64_t)B * nkv * Lmax * 512 > (16LL << 20);
-    if (nt)
-        hipLaunchKernelGGL(attn_decode_fused_kernel<true>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, (long)slab_stride,
-                           pos, (bf16*)k_cache, (bf16*)v_cache, n_slabs, nh, nkv, Lmax, G, nc, MT, scale, eps, (const bf16*)qn_w, (const bf16*)kn_w, inv_freq,
-                           (bf16*)out, part, counters);
-    else
-        hipLaunchKernelGGL(attn_decode_fused_kernel<false>, dim3(nkv, B, (nc + G - 1) / G), dim3(512), 8 * 8192, (hipStream_t)stream, qkv_slab, (long)ld, (long)slab_stride,
-                           pos, (bf16*)k_cache, (bf16*)v_cache, n_slabs, nh, nkv, Lmax, G, nc, MT, scale, eps, (const bf16*)qn_w, (const bf16*)kn_w, inv_freq,
-                           (bf16*)out, part, counters);
+    // More workgroups than the chip has CUs (33-64 rows): four-wave workgroups, two per CU (see W4 at the kernel); same bits.
+    const int groups = (nc + G - 1) / G;
+    const bool w4 = (long)nkv * B * groups > 256 && g_q3_option[Q3ASR_OPT_ATTN_HALF_WG];
+#define ADF_GO(NT_, W4_)                                                                                                                              \
+    hipLaunchKernelGGL((attn_decode_fused_kernel<NT_, W4_>), dim3(nkv, B, groups), dim3(W4_ ? 256 : 512), (W4_ ? 4 : 8) * 8192, (hipStream_t)stream, \
+                       qkv_slab, (long)ld, (long)slab_stride, pos, (bf16*)k_cache, (bf16*)v_cache, n_slabs, nh, nkv, Lmax, G, nc, MT, scale, eps,      \
+                       (const bf16*)qn_w, (const bf16*)kn_w, inv_freq, (bf16*)out, part, counters)
+    if (nt) { if (w4) ADF_GO(true, true); else ADF_GO(true, false); }
+    else { if (w4) ADF_GO(false, true); else ADF_GO(false, false); }
+#undef ADF_GO
     return q3_check_launch("attn_decode_fused");
 }

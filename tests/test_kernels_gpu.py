@@ -843,6 +843,46 @@ def test_attn_decode_fused_is_independent_of_batch_and_capacity(dev):
         assert torch.equal(one[0], full[j])
 
 
+@pytest.mark.parametrize("B,nkv,Lmax,chunks", [(40, 8, 640, 0), (64, 8, 576, 0), (64, 2, 3072, 1), (33, 4, 2560, 1)])
+def test_attn_decode_fused_four_wave_workgroups_give_the_same_bits(dev, B, nkv, Lmax, chunks):
+    """More (sequence, kv head, chunk group) workgroups than the chip has CUs (33-64 rows at 8 kv heads): the launch uses four-wave
+    workgroups, two per CU, each wave computing the partials of two of the eight logical waves (Q3ASR_OPT_ATTN_HALF_WG).  Outputs, appended
+    rows and the workspace state are bit-identical to the eight-wave form -- one chunk per sequence and several (cross-workgroup merge)."""
+    from qwen3_asr_mlx_amd import _lib, ops
+    lib = _lib.load()
+    nh, hd, S = 2 * nkv, 128, 2
+    qkvd = (nh + 2 * nkv) * hd
+    poss = [(p * 197 + 11) % Lmax for p in range(B)]
+    poss[0], poss[1], poss[2] = Lmax - 1, 0, min(Lmax - 1, 470)
+    parts = rnd((S, B, qkvd), dev, 190, 1.0, torch.float32)
+    qn, kn = rnd((hd,), dev, 191) + 1, rnd((hd,), dev, 192) + 1
+    inv = (1e6 ** (-torch.arange(64, dtype=torch.float32) / 64)).to(dev)
+    kc0, vc0 = rnd((B, nkv, Lmax, hd), dev, 193), rnd((B, nkv, Lmax, hd), dev, 194)
+    pos = torch.tensor(poss, dtype=torch.int32, device=dev)
+    res = {}
+    try:
+        if chunks:
+            _lib.call("q3asr_attn_decode_set_chunks_per_wg", chunks)
+        for half in (1, 0):
+            lib.q3asr_set_option(5, half)
+            kc, vc = kc0.clone(), vc0.clone()
+            wsp = torch.zeros((lib.q3asr_attn_decode_fused_workspace(B, nkv, Lmax) // 4,), dtype=torch.float32, device=dev)
+            outs = []
+            for rep in range(2):                                  # the same workspace twice: the arrival counters are left at zero
+                o16 = torch.zeros((nh * hd // 32, ops.mt_of(B), 64, 8), dtype=torch.bfloat16, device=dev)
+                ops.call("q3asr_attn_decode_fused", ops.ptr(parts), qkvd, S, B * qkvd, ops.ptr(qn), ops.ptr(kn), ops.ptr(inv), 1e-6,
+                         ops.ptr(kc), ops.ptr(vc), ops.ptr(pos), ops.ptr(o16), B, nh, nkv, hd, Lmax, hd ** -0.5, ops.ptr(wsp), ops.sp())
+                outs.append(ops.from_x16(o16, B))
+            assert torch.equal(outs[0], outs[1])
+            res[half] = (outs[0], kc, vc)
+    finally:
+        lib.q3asr_set_option(5, 1)
+        _lib.call("q3asr_attn_decode_set_chunks_per_wg", 0)
+    assert nkv * B * (1 if not chunks else (Lmax + 1023) // 1024) > 256        # the case really takes the four-wave form
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    assert bool(torch.isfinite(res[1][0].float()).all())
+
+
 @pytest.mark.parametrize("Lmax", [64, 576, 2560])
 def test_attn_decode_fused_never_uses_cache_rows_at_or_beyond_the_position(dev, Lmax):
     """Rows of the cache at or beyond a sequence's position hold stale or never-written bits (a previous request's rows, a

@@ -60,6 +60,8 @@ for step in "$@"; do
     ab_step)      run 500 $O/${TAG}_ab_step.log python3 $R/tools/ab_step.py ${AB_STEP_ARGS:-32 one=5:0,two=5:1 9} ; grep -v amdgpu.ids $O/${TAG}_ab_step.log | tail -12 ;;
     b1_front)     run 300 $O/${TAG}_b1_front.log python3 $R/tools/b1_front.py ${B1_FRONT_ARGS:-1 30} ; grep -v amdgpu.ids $O/${TAG}_b1_front.log ;;
     ab_epi)       run 500 $O/${TAG}_ab_epi.log python3 $R/tools/ab_gemm_epilogue.py ; grep -v amdgpu.ids $O/${TAG}_ab_epi.log ;;
+    stats5)       rm -rf $O/${TAG}_stats5; run 420 $O/${TAG}_stats5.log rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats5 -- python3 $R/tools/config5_probe.py
+                  find $O/${TAG}_stats5 -name '*kernel_trace.csv' -delete; find $O/${TAG}_stats5 -name '*kernel_stats.csv' -exec head -40 {} \; ; grep config5_probe $O/${TAG}_stats5.log ;;
     ab_sampler)   run 300 $O/${TAG}_ab_sampler.log python3 $R/tools/ab_sampler.py ${AB_SAMPLER_ARGS:-40 5 40} ; grep -v amdgpu.ids $O/${TAG}_ab_sampler.log ;;
     ab_attn)      run 300 $O/${TAG}_ab_attn.log python3 $R/tools/ab_attn.py ${AB_ATTN_ARGS:-3} ; grep -v amdgpu.ids $O/${TAG}_ab_attn.log ;;
     tests_attn)   run 600 $O/${TAG}_tests_attn.log python3 -m pytest $R/tests/test_kernels_gpu.py -m gpu -q -x -k attn ; tail -5 $O/${TAG}_tests_attn.log ;;
