@@ -179,6 +179,8 @@ def sampler_times(model, cfg, B: int, dev, reps: int = 40):
     for name, sm in (("greedy_us", {"temperature": 0.0, "top_p": 1.0}), ("t0.7_top_p0.9_us", {"temperature": 0.7, "top_p": 0.9})):
         ws = DecodeWorkspace(cfg.text_decoder, B, reps + 8, dev, fp8=getattr(dec, "weight_dtype", "bf16") != "bf16")
         ws.logits.copy_((torch.randn(ws.logits.shape, device=dev) * 3.0).to(torch.bfloat16))
+        from qwen3_asr_mlx_amd.tokenizer import EOS_TOKEN_IDS
+        ws.logits[:, sorted(EOS_TOKEN_IDS)] = float("-inf")          # random logits: an EOS draw would end a row in the middle of the timing loop
         ws.max_new.fill_(reps + 8)
         sampling = {"temperature": sm["temperature"], "top_p": sm["top_p"], "top_k": 0, "repetition_penalty": 1.2, "repetition_context_size": 100, "seed": 7}
         dec.sample_step(ws, ws.logits, sampling)
