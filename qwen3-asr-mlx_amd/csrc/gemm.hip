@@ -36,7 +36,7 @@ struct GemmParams {
     void* out; int out_kind; long ldo;                        // 0 bf16, 1 fp32
     const int* row_map;      // optional destination row per m (<0: skip)
     int lds_epi;             // 8-phase kernel: epilogue through the wave-private LDS transpose (host-checked preconditions)
-    // fp8 (OCP e4m3) operands on v_mfma_f32_16x16x32_fp8_fp8 (q3asr_gemm_fp8): A and W are bytes, C = (A8 . W8^T) * a_scale[m] * w_scale[n]
+    // fp8 (OCP e4m3) operands on v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (q3asr_gemm_fp8): A and W are bytes, C = (A8 . W8^T) * a_scale[m] * w_scale[n]
     const float* a_scale; const float* w_scale;
     unsigned long long* stamp;   // diagnostic (q3asr_gemm_set_stamp): workgroup stamp_wg records wall_clock64() at its phase boundaries
     int stamp_wg;
@@ -751,26 +751,34 @@ __device__ __forceinline__ void g8_read_b(const G8Ctx& c, bf16x8 (&bf)[2][2]) {
 }
 template <int MH, int NH, bool F8 = false, int MI1 = 4, int MIA = 4 + MI1>   // MI1: 16-row tiles in the second M half of a wave (4; 3: 112-row wave row; 2: 96-row); MIA: array rows
 __device__ __forceinline__ void g8_mfma(f32x4 (&acc)[4][MIA], const bf16x8 (&af)[4][2], const bf16x8 (&bf)[2][2]) {
+    if constexpr (F8) {
+        // fp8: ONE v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit block scales) per output tile and half-tile of K: the CDNA4
+        // instruction that runs fp8 at twice the bf16 rate (the plain 16x16x32 fp8_fp8 form, four per 128 k, runs at the bf16 rate:
+        // MI355X_MICROARCH.md, matrix cores).  Lane (g, i) supplies 32 bytes of row / column i: its two 16-byte fragments of the
+        // tile row (chunks g and g ^ 4), the same bytes for A and W, i.e. one permutation of k applied to both sides, which a sum over
+        // k does not see (lane map checked with exact integers: tools/micro/mfma128_probe.hip).
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        typedef int v8i __attribute__((ext_vector_type(8)));
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int ii = 0; ii < (MH ? MI1 : 4); ++ii)
+        for (int ii = 0; ii < (MH ? MI1 : 4); ++ii) {
+            const v8i a = __builtin_shufflevector(__builtin_bit_cast(v4i, af[ii][0]), __builtin_bit_cast(v4i, af[ii][1]), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                if constexpr (F8) {
-                    // a 16-byte fragment = two 8-byte fp8 operands: the same byte ranges of a tile row feed both sides, i.e. one
-                    // permutation of k applied to A and W alike, which a sum over k does not see
-                    typedef long l64x2 __attribute__((ext_vector_type(2)));
-                    const l64x2 wb = __builtin_bit_cast(l64x2, bf[jj][kk]), ab = __builtin_bit_cast(l64x2, af[ii][kk]);
-                    f32x4 t = acc[NH * 2 + jj][MH * 4 + ii];
-                    t = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[0], ab[0], t, 0, 0, 0);
-                    t = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[1], ab[1], t, 0, 0, 0);
-                    acc[NH * 2 + jj][MH * 4 + ii] = t;
-                } else {
+                const v8i w = __builtin_shufflevector(__builtin_bit_cast(v4i, bf[jj][0]), __builtin_bit_cast(v4i, bf[jj][1]), 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[NH * 2 + jj][MH * 4 + ii] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, acc[NH * 2 + jj][MH * 4 + ii], 0, 0, 0, 0x7F7F7F7F,
+                                                                                                 0, 0x7F7F7F7F);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ii = 0; ii < (MH ? MI1 : 4); ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
                     acc[NH * 2 + jj][MH * 4 + ii] =
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jj][kk], af[ii][kk], acc[NH * 2 + jj][MH * 4 + ii], 0, 0, 0);
-                }
-            }
+    }
 }
 
 // One phase.  PH = g & 7; `tile` = K tile whose half-tile S[g+7] is issued ((g + 7) >> 2).
@@ -1118,9 +1126,9 @@ extern "C" int q3asr_conv3x3s2_bf16(const void* x, int imgs, int Hin, int Win, i
 // fp8 x fp8 GEMM on the CDNA4 fp8 MFMA (BASELINE.json configs[4]):  C[M,N] = (A8 . W8^T) * a_scale[m] * w_scale[n], then the
 // same epilogues as q3asr_gemm_bf16 (SwiGLU, bf16 residual).  A8 = activations quantised per token (row) to OCP e4m3 by
 // q3asr_rmsnorm_bf16_fp8 / q3asr_quantize_rows_fp8, W8 = the checkpoint weight quantised per output row at load.  Runs on the
-// 8-phase kernel: a tile row is 128 bytes = 128 k (64 for bf16), every 16-byte fragment feeds two
-// v_mfma_f32_16x16x32_fp8_fp8, so per unit of K the MFMA work is that of the bf16 kernel and the LDS / L2 / HBM operand
-// bytes are half.
+// 8-phase kernel: a tile row is 128 bytes = 128 k (64 for bf16); a lane's two 16-byte fragments of a row are one operand of
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales), so per unit of K the MFMA cycles AND the LDS / L2 / HBM operand bytes are half
+// those of the bf16 kernel (rounds 2-4 issued four v_mfma_f32_16x16x32_fp8_fp8 per 128 k, which run at the bf16 rate).
 // ---------------------------------------------------------------------------
 extern "C" int q3asr_gemm_fp8(const void* A8, int64_t lda, const float* a_scale, const void* W8, int64_t ldw, const float* w_scale,
                               int M, int N, int K, int act, const void* res, int res_kind, int64_t ldres, void* out, int64_t ldo,
