@@ -30,7 +30,7 @@ between("DESIGN.md", "Headline on the driver-equivalent line of this round", "| 
         f"""Headline on the driver-equivalent line of this round (`profiles/r05_bench_line.json`, library `{lib}`, one MI355X): **{f(V['rtf'])} x real time,
 {V['ms']:.1f} ms per 32 x 30 s request** (round 4: 3,952 x / 242.9 ms; {rng}), `end_to_end`
 {V['e2e']:.1f} ms (+{V['dres']:.1f} ms: {V['fill']:.1f} ms host fill + {V['span']:.1f} ms copy at {V['gbps']:.0f} GB/s; five recorded runs per staging form, {min(V['runs']):.1f}-{max(V['runs']):.1f} and {min(V['oruns']):.1f}-{max(V['oruns']):.1f} ms), batch-1 {V['b1']:.1f} ms,
-two / four requests in flight {f(V['f2'])} x / {f(V['f4'])} x, `longform_fp8` (configs[4]) **{f(V['lf'])} x** ({V['lfms']:.1f} ms for 20 min of audio; 279.9-284.1 ms before the four-wave decode attention, 3,853 x / 311.4 ms before the rows
+two / four requests in flight {f(V['f2'])} x / {f(V['f4'])} x, `longform_fp8` (configs[4]) **{f(V['lf'])} x** ({V['lfms']:.1f} ms for 20 min of audio; 279.9-284.1 ms before the four-wave decode attention and the 128-wide fp8 MFMA, 3,853 x / 311.4 ms before the rows
 marked "+" below), encoder {V['enc']:.1f} ms (15.17), prefill {V['pre']:.1f} ms, decode {V['dec']:.3f} ms per token (1.504 before the last "+" rows; its floor is section 0a).
 
 """)
