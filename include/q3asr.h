@@ -105,7 +105,7 @@ int q3asr_layernorm_f32_split3(const float* x, const float* w, const float* b, v
 int q3asr_attn_fwd_f32(const float* qkv, int64_t ld, int d_model, const int32_t* seg_start, const int32_t* seg_len, int n_segs,
                        int max_len, int n_heads, float scale, float* out, int64_t ldo, void* stream);
 
-/* ---- fp8 (OCP e4m3) GEMM on v_mfma_f32_16x16x32_fp8_fp8 (BASELINE.json configs[4]: prefill projections of
+/* ---- fp8 (OCP e4m3) GEMM on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (BASELINE.json configs[4]: prefill projections of
  * decoder.py:92-97,136-165 with fp8 weights): C = (A8 . W8^T) * a_scale[m] * w_scale[n] -> bf16 [M][ldo].
  * A8 bytes [M][lda] (per-token scale a_scale[M], from the two quantisers below), W8 bytes [N][ldw] (per-row scale w_scale[N]).
  * act: 0 none, 2 SwiGLU (weights interleaved as for q3asr_gemm_bf16); res_kind: 0 none, 2 bf16 residual. */

@@ -306,7 +306,7 @@ def test_gemm_8phase_is_stable_under_load(dev, mode):
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (1000, 768, 1024), (4396, 2048, 2048), (130, 1024, 6144)])
 def test_gemm_fp8_on_the_fp8_mfma(dev, M, N, K):
-    """q3asr_gemm_fp8: per-token quantised activations x per-row quantised weights on v_mfma_f32_16x16x32_fp8_fp8 against
+    """q3asr_gemm_fp8: per-token quantised activations x per-row quantised weights on v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) against
     the same product in float64 of the dequantised operands (exact inputs: only the fp32 accumulation order differs), plain,
     with the bf16 residual and through SwiGLU; the quantisers against torch's e4m3 conversion."""
     from qwen3_asr_mlx_amd import ops
